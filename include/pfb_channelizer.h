@@ -1,0 +1,190 @@
+/*
+ * pfb_channelizer.h -- C ABI of the MI355X polyphase-filterbank channelizer.
+ *
+ * This is the drop-in boundary for the reference's channelizer path.  The
+ * reference has no FFI for it: the path is MATLAB script code around MathWorks'
+ * dsp.Channelizer.  Each entry point below names the reference lines it
+ * replaces (paths relative to /root/reference):
+ *
+ *   pfb_create            dsp.Channelizer(M) construction
+ *                         matlab/channelizer_example.m:29-31
+ *                         matlab/create_pdws_channelized.m:31-33
+ *                         matlab/generate_channelized_training_iq.m:95-98
+ *   pfb_process*          int->complex normalise + (conj) transpose + truncate +
+ *                         channelizer(x) + fftshift(.,2)
+ *                         matlab/channelizer_example.m:18-23,56,58
+ *                         matlab/create_pdws_channelized.m:35-60
+ *                         input buffer = what the recorders hold:
+ *                         cpp/blade_record_iq_12bit.cpp:268,322 (&iq[FILTER_DELAY])
+ *                         cpp/usrp_record_iq_08bit.cpp:179,226
+ *   pfb_reset             a fresh dsp.Channelizer per file
+ *                         matlab/create_pdws_channelized.m:33
+ *   pfb_center_frequencies  centerFrequencies(channelizer, fs)
+ *                         matlab/channelizer_example.m:60
+ *                         matlab/create_pdws_channelized.m:42
+ *   pfb_strerror          bladerf_strerror(status) convention
+ *                         cpp/blade_record_iq_12bit.cpp:56-60
+ *
+ * Conventions follow the recorders: every call returns an int status, 0 = OK,
+ * negative = failure (never throws, never aborts); the caller owns sample and
+ * output buffers; a handle is used by one thread at a time.
+ *
+ * Arithmetic:
+ *   x[n]   = (I[n] + jQ[n]) / 2^(bit_width-1)
+ *   y_k[m] = sum_{n=0}^{MP-1} taps[n] e^{+j2 pi k n/M} x[m D + input_offset - n]
+ * computed in fp32 on the GPU as M polyphase branches + an M-point FFT.
+ * The handle is stateful like the MATLAB System object: samples from earlier
+ * calls are the x[n<0] of later ones, and a call whose length is not a multiple
+ * of D carries its tail to the next call.
+ *
+ * There is NO CPU fallback: without a HIP device every compute entry point
+ * returns PFB_ERR_NO_DEVICE.
+ */
+#ifndef PFB_CHANNELIZER_H
+#define PFB_CHANNELIZER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "pfb_iq_packet.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFB_ABI_VERSION 1
+
+typedef enum pfb_status {
+  PFB_OK = 0,
+  PFB_ERR_BAD_ARG = -1,      /* null pointer, size mismatch, value out of range      */
+  PFB_ERR_BAD_FORMAT = -2,   /* unknown .iq marker / sample format / bit width       */
+  PFB_ERR_UNSUPPORTED = -3,  /* configuration the library has no kernel for          */
+  PFB_ERR_NO_DEVICE = -4,    /* no HIP device / HIP runtime unavailable              */
+  PFB_ERR_HIP = -5,          /* a HIP call failed (pfb_last_error_detail has more)   */
+  PFB_ERR_NO_MEMORY = -6,
+  PFB_ERR_CAPACITY = -7      /* output buffer smaller than the frames produced       */
+} pfb_status;
+
+typedef enum pfb_sample_format {
+  PFB_FMT_INT8_IQ = 0,   /* std::complex<int8_t>  (blade/usrp_record_iq_08bit.cpp)   */
+  PFB_FMT_INT16_IQ = 1,  /* std::complex<int16_t> (blade/usrp_record_iq_12bit.cpp)   */
+  PFB_FMT_CF32 = 2       /* interleaved float I,Q, already normalised                */
+} pfb_sample_format;
+
+typedef enum pfb_output_layout {
+  PFB_LAYOUT_FRAME_MAJOR = 0,   /* out[m*M + k]      (row-major F x M)               */
+  PFB_LAYOUT_CHANNEL_MAJOR = 1  /* out[k*F + m]      (MATLAB's column-major F x M)   */
+} pfb_output_layout;
+
+enum {
+  PFB_FLAG_FFTSHIFT = 1u << 0,        /* fftshift(out,2): create_pdws_channelized.m:60 */
+  PFB_FLAG_CONJUGATE_INPUT = 1u << 1, /* iq' quirk: channelizer_example.m:23           */
+  PFB_FLAG_DEROTATE = 1u << 2         /* y_k[m] *= e^{-j2 pi k m D/M} (identity if D=M) */
+};
+
+enum {
+  PFB_MEM_HOST = 0,   /* iq/out are host pointers: the library stages them            */
+  PFB_MEM_DEVICE = 1  /* iq/out are device pointers on the handle's GPU               */
+};
+
+typedef struct pfb_config {
+  uint32_t struct_size;        /* = sizeof(pfb_config), for ABI growth               */
+  uint32_t num_channels;       /* M  (reference: fs*1e-6, channelizer_example.m:29)  */
+  uint32_t taps_per_channel;   /* P  (dsp.Channelizer default 12)                    */
+  uint32_t decimation;         /* D: 0 or M = maximally decimated, M/2 = 2x oversampled */
+  const float* taps;           /* M*P prototype taps h[n], copied at create          */
+  uint32_t sample_format;      /* pfb_sample_format                                  */
+  uint32_t bit_width;          /* 8, 12 or 16: scale 2^-(bit_width-1); ignored for CF32 */
+  uint32_t output_layout;      /* pfb_output_layout                                  */
+  uint32_t flags;              /* PFB_FLAG_*                                         */
+  int32_t  input_offset;       /* 0..D-1, or -1 for the default D-1                  */
+  int32_t  device_id;          /* HIP device ordinal, -1 = current device            */
+} pfb_config;
+
+typedef struct pfb_handle pfb_handle;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+int pfb_create(const pfb_config* cfg, pfb_handle** out);
+int pfb_destroy(pfb_handle* h);
+/* zero the filter state, the carried tail and the frame counter */
+int pfb_reset(pfb_handle* h);
+/* launch on this hipStream_t from now on (default: the null stream) */
+int pfb_set_stream(pfb_handle* h, void* hip_stream);
+
+/* ---- process -------------------------------------------------------------- */
+/* Channelize num_samples complex samples.  `iq` is the recorder's buffer
+ * (interleaved I,Q of cfg.sample_format).  Frames produced =
+ * floor((carried + num_samples)/D) is written to *frames_out; `out` receives
+ * frames*M complex64 values and must hold at least out_capacity_frames frames
+ * (PFB_ERR_CAPACITY otherwise, with *frames_out = frames needed and no state
+ * change).  With PFB_LAYOUT_CHANNEL_MAJOR the column stride is the number of
+ * frames of this call.  Synchronous: results are complete on return. */
+int pfb_process(pfb_handle* h, const void* iq, uint64_t num_samples, void* out,
+                uint64_t out_capacity_frames, uint64_t* frames_out, uint32_t mem);
+/* Same, device pointers only, enqueued on the handle's stream without a host
+ * sync.  The input buffer must stay valid until pfb_sync (the state update
+ * reads its tail on the stream). */
+int pfb_process_async(pfb_handle* h, const void* d_iq, uint64_t num_samples, void* d_out,
+                      uint64_t out_capacity_frames, uint64_t* frames_out);
+int pfb_sync(pfb_handle* h);
+/* Frames a call with num_samples would produce right now. */
+int pfb_frames_for(const pfb_handle* h, uint64_t num_samples, uint64_t* frames_out);
+
+/* ---- state (checkpoint/resume, and the multi-GPU halo) --------------------- */
+/* History is the raw input samples (cfg.sample_format) that precede the next
+ * call: pfb_history_samples() of them.  A time shard on GPU g>0 is primed with
+ * the last pfb_history_samples() samples of shard g-1. */
+uint64_t pfb_history_samples(const pfb_handle* h);
+/* Feed samples into the history without producing output (n may be any size;
+ * only the trailing pfb_history_samples() matter).  Carried-tail phase is
+ * advanced by n exactly as pfb_process would. */
+int pfb_prime(pfb_handle* h, const void* iq, uint64_t num_samples, uint32_t mem);
+/* Opaque state blob: history + counters.  Query size with buf == NULL. */
+int pfb_get_state(pfb_handle* h, void* buf, size_t* bytes);
+int pfb_set_state(pfb_handle* h, const void* buf, size_t bytes);
+/* Global index of the next frame (used by PFB_FLAG_DEROTATE); settable so a
+ * time shard can start mid-stream. */
+int pfb_set_frame_index(pfb_handle* h, uint64_t next_frame);
+int pfb_get_frame_index(const pfb_handle* h, uint64_t* next_frame);
+
+/* ---- helpers -------------------------------------------------------------- */
+/* centerFrequencies(channelizer, fs): out[k], unshifted order
+ * [0,1,..,ceil(M/2)-1,-floor(M/2),..,-1]*fs/M. */
+int pfb_center_frequencies(uint32_t num_channels, double fs, double* out);
+/* Convenience prototype: Kaiser-windowed sinc, M*P taps, cutoff fs/(2M).
+ * NOT verified against MathWorks' internal design -- pass your own taps for
+ * parity work. */
+int pfb_design_prototype(uint32_t num_channels, uint32_t taps_per_channel,
+                         double stopband_atten_db, float* taps_out);
+const char* pfb_strerror(int status);
+/* Text of the most recent HIP failure on this thread ("" if none). */
+const char* pfb_last_error_detail(void);
+int pfb_abi_version(void);
+int pfb_device_count(void);
+
+/* ---- tuning / introspection (stable names, values may grow) ---------------- */
+typedef enum pfb_option {
+  PFB_OPT_KERNEL = 0,           /* 0 = auto, 1 = force generic kernel, 2 = require fast kernel */
+  PFB_OPT_FRAMES_PER_BLOCK = 1, /* run length per workgroup for the fast kernels (0 = default) */
+  PFB_OPT_HOST_CHUNK_SAMPLES = 2, /* staging chunk for PFB_MEM_HOST (0 = default)              */
+  PFB_OPT_NONTEMPORAL = 3,      /* 1 = nontemporal output stores                               */
+  PFB_OPT_PROFILE = 4           /* 1 = bracket every channelizer kernel launch with HIP events  */
+} pfb_option;
+int pfb_set_option(pfb_handle* h, int option, int64_t value);
+/* With PFB_OPT_PROFILE on: durations (ms) of the channelizer kernel launches
+ * since the option was set or since the last call of this function, measured
+ * by hipEvents recorded on the handle's stream immediately around each launch
+ * (oldest first, at most 4096 kept).  Synchronises the stream.  *count receives
+ * the number written (<= capacity). */
+int pfb_get_kernel_times(pfb_handle* h, float* ms_out, int capacity, int* count);
+/* Name of the kernel the last process call launched ("" before the first). */
+const char* pfb_last_kernel(const pfb_handle* h);
+/* Device stream-copy (read 1 : write 2, like cfg 2's traffic) timed with HIP
+ * events: bytes moved per second, for the "measured peak" next to the nominal
+ * roofline.  Uses `bytes_in` of input and 2*bytes_in of output scratch. */
+int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double* bytes_per_sec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,206 @@
+"""Host-side mirror of the reference's channelizer usage, over the C ABI.
+
+The reference drives MathWorks' ``dsp.Channelizer`` from script code:
+
+    channelizer = dsp.Channelizer(numBands)        channelizer_example.m:31
+    out = channelizer(iq)                          channelizer_example.m:56
+    zeroCenterOut = fftshift(out, 2)               channelizer_example.m:58
+    f = centerFrequencies(channelizer, fs)         channelizer_example.m:60
+
+``Channelizer`` keeps those names and meanings (constructor takes the band
+count, the object is callable and stateful, ``centerFrequencies(fs)``,
+``reset()``/``release()``), but consumes the recorders' raw integer I/Q
+directly -- the normalise step (channelizer_example.m:18-21) is fused into the
+kernel -- and runs on the GPU through libpfb_channelizer.so.  Nothing here
+computes on the CPU: without the library or a HIP device it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_FMT = {"int8": L.PFB_FMT_INT8_IQ, "int16": L.PFB_FMT_INT16_IQ, "cf32": L.PFB_FMT_CF32}
+_NP_DTYPE = {L.PFB_FMT_INT8_IQ: np.int8, L.PFB_FMT_INT16_IQ: np.int16, L.PFB_FMT_CF32: np.float32}
+
+
+def design_prototype(num_bands: int, taps_per_band: int = 12, stopband_atten: float = 80.0) -> np.ndarray:
+    """Convenience Kaiser-windowed-sinc prototype (NOT verified against MathWorks' design)."""
+    h = np.empty(num_bands * taps_per_band, dtype=np.float32)
+    L.check(L.load().pfb_design_prototype(num_bands, taps_per_band, stopband_atten,
+                                          h.ctypes.data_as(C.POINTER(C.c_float))), "pfb_design_prototype")
+    return h
+
+
+def center_frequencies(num_bands: int, fs: float) -> np.ndarray:
+    out = np.empty(num_bands, dtype=np.float64)
+    L.check(L.load().pfb_center_frequencies(num_bands, fs, out.ctypes.data_as(C.POINTER(C.c_double))),
+            "pfb_center_frequencies")
+    return out
+
+
+class Channelizer:
+    """``dsp.Channelizer``-shaped front end of the MI355X polyphase filterbank.
+
+    Parameters mirror the System object where it has them (NumFrequencyBands,
+    NumTapsPerBand, StopbandAttenuation, DecimationFactor) plus what the raw
+    I/Q path needs (sample_format / bit_width from the IqPacket header).
+    """
+
+    def __init__(self, num_bands: int, *, taps: np.ndarray | None = None, taps_per_band: int = 12,
+                 stopband_atten: float = 80.0, decimation: int | None = None, sample_format: str = "int16",
+                 bit_width: int = 12, channel_major: bool = False, fftshift: bool = False,
+                 conjugate_input: bool = False, derotate: bool = False, input_offset: int = -1,
+                 device: int = -1):
+        self._h = C.c_void_p()
+        lib = L.load()
+        M = int(num_bands)
+        if taps is None:
+            taps = design_prototype(M, taps_per_band, stopband_atten)
+        taps = np.ascontiguousarray(taps, dtype=np.float32).reshape(-1)
+        if taps.size % M:
+            raise ValueError("taps must hold num_bands * taps_per_band coefficients")
+        self.num_bands = M
+        self.taps_per_band = taps.size // M
+        self.decimation = M if decimation is None else int(decimation)
+        self.taps = taps
+        self.fmt = _FMT[sample_format]
+        self.bit_width = int(bit_width)
+        self.channel_major = bool(channel_major)
+        self.device = device
+        flags = (L.PFB_FLAG_FFTSHIFT if fftshift else 0) | (L.PFB_FLAG_CONJUGATE_INPUT if conjugate_input else 0) \
+            | (L.PFB_FLAG_DEROTATE if derotate else 0)
+        cfg = L.PfbConfig(C.sizeof(L.PfbConfig), M, self.taps_per_band, self.decimation,
+                          taps.ctypes.data_as(C.POINTER(C.c_float)), self.fmt, self.bit_width,
+                          L.PFB_LAYOUT_CHANNEL_MAJOR if channel_major else L.PFB_LAYOUT_FRAME_MAJOR, flags,
+                          int(input_offset), int(device))
+        L.check(lib.pfb_create(C.byref(cfg), C.byref(self._h)), "pfb_create")
+        self._lib = lib
+
+    # -- lifecycle ---------------------------------------------------------------
+    def release(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pfb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    close = release
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+
+    def reset(self) -> None:
+        L.check(self._lib.pfb_reset(self._h), "pfb_reset")
+
+    # -- helpers -----------------------------------------------------------------
+    def centerFrequencies(self, fs: float) -> np.ndarray:  # noqa: N802 (reference name)
+        return center_frequencies(self.num_bands, fs)
+
+    def frames_for(self, num_samples: int) -> int:
+        f = C.c_uint64()
+        L.check(self._lib.pfb_frames_for(self._h, num_samples, C.byref(f)), "pfb_frames_for")
+        return int(f.value)
+
+    @property
+    def history_samples(self) -> int:
+        return int(self._lib.pfb_history_samples(self._h))
+
+    def set_option(self, option: int, value: int) -> None:
+        L.check(self._lib.pfb_set_option(self._h, option, value), "pfb_set_option")
+
+    @property
+    def last_kernel(self) -> str:
+        return self._lib.pfb_last_kernel(self._h).decode()
+
+    def set_stream(self, hip_stream: int) -> None:
+        L.check(self._lib.pfb_set_stream(self._h, C.c_void_p(hip_stream)), "pfb_set_stream")
+
+    def set_frame_index(self, next_frame: int) -> None:
+        L.check(self._lib.pfb_set_frame_index(self._h, next_frame), "pfb_set_frame_index")
+
+    def get_state(self) -> bytes:
+        n = C.c_size_t(0)
+        L.check(self._lib.pfb_get_state(self._h, None, C.byref(n)), "pfb_get_state")
+        buf = C.create_string_buffer(n.value)
+        L.check(self._lib.pfb_get_state(self._h, buf, C.byref(n)), "pfb_get_state")
+        return buf.raw[: n.value]
+
+    def set_state(self, blob: bytes) -> None:
+        L.check(self._lib.pfb_set_state(self._h, blob, len(blob)), "pfb_set_state")
+
+    # -- samples -----------------------------------------------------------------
+    def _host_samples(self, iq: np.ndarray) -> tuple[np.ndarray, int]:
+        want = _NP_DTYPE[self.fmt]
+        a = np.asarray(iq)
+        if self.fmt == L.PFB_FMT_CF32 and np.iscomplexobj(a):
+            a = np.ascontiguousarray(a, dtype=np.complex64).view(np.float32)
+        if a.dtype != want:
+            raise TypeError(f"expected {np.dtype(want)} I/Q for this channelizer, got {a.dtype}")
+        a = np.ascontiguousarray(a).reshape(-1)
+        if a.size % 2:
+            raise ValueError("interleaved I,Q needs an even element count")
+        return a, a.size // 2
+
+    def _is_torch(self, x) -> bool:
+        return type(x).__module__.startswith("torch")
+
+    def prime(self, iq) -> None:
+        """Feed history without producing output (time-shard halo, resume)."""
+        if self._is_torch(iq) and iq.is_cuda:
+            n = iq.numel() // 2 if not iq.is_complex() else iq.numel()
+            L.check(self._lib.pfb_prime(self._h, C.c_void_p(iq.data_ptr()), n, L.PFB_MEM_DEVICE), "pfb_prime")
+            return
+        a, n = self._host_samples(iq)
+        L.check(self._lib.pfb_prime(self._h, C.c_void_p(a.ctypes.data), n, L.PFB_MEM_HOST), "pfb_prime")
+
+    def __call__(self, iq, out=None, sync: bool = True):
+        """Channelize one buffer.  numpy in -> numpy out (staged through the GPU);
+        torch CUDA tensor in -> torch CUDA tensor out (no copies).
+        Returns complex64 of shape (frames, M), or (M, frames) when channel_major."""
+        M = self.num_bands
+        if self._is_torch(iq) and iq.is_cuda:
+            import torch
+            if not iq.is_contiguous():
+                raise ValueError("device I/Q must be contiguous")
+            n = iq.numel() if iq.is_complex() else iq.numel() // 2
+            F = self.frames_for(n)
+            shape = (M, F) if self.channel_major else (F, M)
+            if out is None:
+                out = torch.empty(shape, dtype=torch.complex64, device=iq.device)
+            elif out.numel() < F * M or out.dtype != torch.complex64 or not out.is_contiguous():
+                raise ValueError("out must be a contiguous complex64 tensor with room for frames*M values")
+            f = C.c_uint64()
+            fn = self._lib.pfb_process if sync else self._lib.pfb_process_async
+            args = [self._h, C.c_void_p(iq.data_ptr()), n, C.c_void_p(out.data_ptr()), F, C.byref(f)]
+            if sync:
+                args.append(L.PFB_MEM_DEVICE)
+            L.check(fn(*args), "pfb_process")
+            return out if out.shape == shape else out.reshape(-1)[: F * M].reshape(shape)
+        a, n = self._host_samples(iq)
+        F = self.frames_for(n)
+        shape = (M, F) if self.channel_major else (F, M)
+        res = np.empty(shape, dtype=np.complex64) if out is None else out
+        f = C.c_uint64()
+        L.check(self._lib.pfb_process(self._h, C.c_void_p(a.ctypes.data), n, C.c_void_p(res.ctypes.data), F,
+                                      C.byref(f), L.PFB_MEM_HOST), "pfb_process")
+        return res
+
+    def kernel_times_ms(self) -> list[float]:
+        """Durations of the channelizer kernel launches recorded since PFB_OPT_PROFILE was set."""
+        buf = (C.c_float * 4096)()
+        n = C.c_int(0)
+        L.check(self._lib.pfb_get_kernel_times(self._h, buf, 4096, C.byref(n)), "pfb_get_kernel_times")
+        return list(buf[: n.value])
+
+    def sync(self) -> None:
+        L.check(self._lib.pfb_sync(self._h), "pfb_sync")

@@ -1,0 +1,569 @@
+// pfb_api.cpp -- host side of the C ABI in include/pfb_channelizer.h.
+//
+// Owns: the handle (taps, twiddles, history, counters), kernel selection, the
+// host-pointer staging path and the state blob.  All arithmetic is in
+// pfb_kernels.hip; there is deliberately no CPU implementation here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pfb_common.h"
+
+namespace {
+
+thread_local std::string g_detail;
+
+int hip_fail(hipError_t e, const char* what) {
+  char buf[256];
+  std::snprintf(buf, sizeof(buf), "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+  g_detail = buf;
+  (void)hipGetLastError();  // clear the sticky error
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+             ? PFB_ERR_NO_DEVICE
+             : (e == hipErrorOutOfMemory ? PFB_ERR_NO_MEMORY : PFB_ERR_HIP);
+}
+
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    const hipError_t e__ = (expr);                     \
+    if (e__ != hipSuccess) return hip_fail(e__, #expr); \
+  } while (0)
+
+struct DeviceGuard {  // run on the handle's device, restore the caller's afterwards
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+constexpr uint32_t kStateMagic = 0x50464231u;  // "PFB1"
+
+struct StateHeader {
+  uint32_t magic, M, P, D, fmt, hist_samples, phase, reserved;
+  uint64_t frame_index;
+};
+
+}  // namespace
+
+struct pfb_handle {
+  int M = 0, P = 0, D = 0, off = 0;
+  int fmt = 0, bit_width = 0, layout = 0;
+  unsigned flags = 0;
+  int device = 0;
+  int bps = 0;             // bytes per input sample
+  int hist_samples = 0;    // M*P + D
+  float* d_taps = nullptr;   // M*P, scaled by 2^-(bit_width-1)
+  float2* d_tw = nullptr;    // M
+  void* d_hist[2] = {nullptr, nullptr};
+  int cur = 0;               // which history buffer is current
+  uint32_t phase = 0;        // samples carried since the last frame boundary (0..D-1)
+  uint64_t frame_index = 0;  // global index of the next frame
+  hipStream_t stream = nullptr;
+  const pfb::FastKernelInfo* fast = nullptr;
+  // options
+  int opt_kernel = 0;
+  int opt_frames_per_block = 0;
+  int64_t opt_host_chunk = 0;
+  int opt_nontemporal = 0;
+  const char* last_kernel = "";
+  // host staging
+  void* d_stage_in = nullptr;
+  void* d_stage_out = nullptr;
+  size_t stage_in_bytes = 0, stage_out_bytes = 0;
+  // PFB_OPT_PROFILE: event pairs around each channelizer kernel launch
+  int opt_profile = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // reusable pairs
+  size_t ev_used = 0;
+};
+
+namespace {
+
+void free_handle(pfb_handle* h) {
+  if (!h) return;
+  DeviceGuard g(h->device);
+  (void)hipFree(h->d_taps);
+  (void)hipFree(h->d_tw);
+  (void)hipFree(h->d_hist[0]);
+  (void)hipFree(h->d_hist[1]);
+  (void)hipFree(h->d_stage_in);
+  (void)hipFree(h->d_stage_out);
+  for (auto& pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  delete h;
+}
+
+uint64_t frames_for(const pfb_handle* h, uint64_t n) { return (h->phase + n) / (uint64_t)h->D; }
+
+// enqueue kernel + history update for device-resident buffers; no host sync
+int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t frames, int64_t out_ld,
+            int64_t out_frame0) {
+  if (frames > 0) {
+    pfb::KernelParams p{};
+    p.in = d_iq;
+    p.hist = h->d_hist[h->cur];
+    p.out = static_cast<float2*>(d_out);
+    p.taps = h->d_taps;
+    p.tw = h->d_tw;
+    p.n_in = (long long)n;
+    p.frames = (long long)frames;
+    p.frame0 = (long long)h->frame_index;
+    p.out_ld = out_ld;
+    p.out_frame0 = out_frame0;
+    p.base = (h->off - (int)h->phase) - (h->D - 1);
+    p.hist_samples = h->hist_samples;
+    p.M = h->M; p.P = h->P; p.D = h->D;
+    p.fmt = h->fmt;
+    p.layout = h->layout;
+    p.flags = h->flags;
+    p.nontemporal = h->opt_nontemporal;
+    const bool want_fast = h->fast && h->layout == PFB_LAYOUT_FRAME_MAJOR && h->opt_kernel != 1;
+    if (h->opt_kernel == 2 && !want_fast) return PFB_ERR_UNSUPPORTED;
+    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+    if (h->opt_profile && h->ev_used < 4096) {
+      if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        h->ev_pool.emplace_back(a, b);
+      }
+      ev = &h->ev_pool[h->ev_used++];
+      HIP_TRY(hipEventRecord(ev->first, h->stream));
+    }
+    if (want_fast) {
+      const int c = h->fast->chunk_frames;
+      int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
+      fpb = ((fpb + c - 1) / c) * c;
+      p.frames_per_block = fpb;
+      const int cpt = h->fast->cols_per_thread;
+      const int bmod = ((p.base % cpt) + cpt) % cpt;
+      p.vec_ok = (bmod == 0) && (reinterpret_cast<uintptr_t>(d_iq) % (uintptr_t)(h->bps * cpt) == 0);
+      HIP_TRY(h->fast->launch(p, h->stream));
+      h->last_kernel = h->fast->name;
+    } else {
+      HIP_TRY(pfb::launch_generic(p, h->stream));
+      h->last_kernel = "pfb_generic";
+    }
+    if (ev) HIP_TRY(hipEventRecord(ev->second, h->stream));
+  }
+  if (n > 0) {
+    HIP_TRY(pfb::launch_update_history(h->d_hist[h->cur], d_iq, (long long)n, h->d_hist[h->cur ^ 1],
+                                       h->hist_samples, h->bps, h->stream));
+    h->cur ^= 1;
+  }
+  h->phase = (uint32_t)((h->phase + n) % (uint64_t)h->D);
+  h->frame_index += frames;
+  return PFB_OK;
+}
+
+int ensure_stage(pfb_handle* h, size_t in_bytes, size_t out_bytes) {
+  if (in_bytes > h->stage_in_bytes) {
+    (void)hipFree(h->d_stage_in);
+    h->d_stage_in = nullptr; h->stage_in_bytes = 0;
+    HIP_TRY(hipMalloc(&h->d_stage_in, in_bytes));
+    h->stage_in_bytes = in_bytes;
+  }
+  if (out_bytes > h->stage_out_bytes) {
+    (void)hipFree(h->d_stage_out);
+    h->d_stage_out = nullptr; h->stage_out_bytes = 0;
+    HIP_TRY(hipMalloc(&h->d_stage_out, out_bytes));
+    h->stage_out_bytes = out_bytes;
+  }
+  return PFB_OK;
+}
+
+int process_host(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t frames_total) {
+  // Stage through device buffers in chunks (multiples of D so chunks never change the carried phase
+  // pattern mid-call beyond what the stream semantics already define).
+  uint64_t chunk = h->opt_host_chunk > 0 ? (uint64_t)h->opt_host_chunk : (uint64_t)1 << 24;
+  chunk = ((chunk + h->D - 1) / h->D) * h->D;
+  const uint64_t max_frames = chunk / h->D + 1;
+  const int rc = ensure_stage(h, (size_t)std::min<uint64_t>(chunk, n ? n : 1) * h->bps,
+                              (size_t)std::min<uint64_t>(max_frames, frames_total ? frames_total : 1) * h->M *
+                                  sizeof(float2));
+  if (rc != PFB_OK) return rc;
+  const char* src = static_cast<const char*>(iq);
+  char* dst = static_cast<char*>(out);
+  uint64_t done = 0, frames_done = 0;
+  while (done < n) {
+    const uint64_t m = std::min<uint64_t>(chunk, n - done);
+    const uint64_t f = frames_for(h, m);
+    HIP_TRY(hipMemcpyAsync(h->d_stage_in, src + done * h->bps, (size_t)m * h->bps, hipMemcpyHostToDevice, h->stream));
+    const int rc2 = enqueue(h, h->d_stage_in, m, h->d_stage_out, f, (int64_t)f, 0);
+    if (rc2 != PFB_OK) return rc2;
+    if (f > 0) {
+      if (h->layout == PFB_LAYOUT_FRAME_MAJOR) {
+        HIP_TRY(hipMemcpyAsync(dst + frames_done * h->M * sizeof(float2), h->d_stage_out,
+                               (size_t)f * h->M * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+      } else {  // column k of this chunk -> rows [frames_done, frames_done+f) of column k of the call
+        HIP_TRY(hipMemcpy2DAsync(dst + frames_done * sizeof(float2), (size_t)frames_total * sizeof(float2),
+                                 h->d_stage_out, (size_t)f * sizeof(float2), (size_t)f * sizeof(float2),
+                                 (size_t)h->M, hipMemcpyDeviceToHost, h->stream));
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));  // staging buffers are reused by the next chunk
+    done += m;
+    frames_done += f;
+  }
+  return PFB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pfb_abi_version(void) { return PFB_ABI_VERSION; }
+
+const char* pfb_last_error_detail(void) { return g_detail.c_str(); }
+
+const char* pfb_strerror(int status) {
+  switch (status) {
+    case PFB_OK: return "ok";
+    case PFB_ERR_BAD_ARG: return "bad argument";
+    case PFB_ERR_BAD_FORMAT: return "bad sample or record format";
+    case PFB_ERR_UNSUPPORTED: return "unsupported configuration";
+    case PFB_ERR_NO_DEVICE: return "no HIP device";
+    case PFB_ERR_HIP: return "HIP runtime error";
+    case PFB_ERR_NO_MEMORY: return "out of memory";
+    case PFB_ERR_CAPACITY: return "output buffer too small";
+    default: return "unknown status";
+  }
+}
+
+int pfb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int pfb_center_frequencies(uint32_t M, double fs, double* out) {
+  if (!out || M == 0) return PFB_ERR_BAD_ARG;
+  for (uint32_t k = 0; k < M; ++k) {
+    const int64_t kk = (k < (M + 1) / 2) ? (int64_t)k : (int64_t)k - (int64_t)M;
+    out[k] = (double)kk * fs / (double)M;
+  }
+  return PFB_OK;
+}
+
+static double bessel_i0(double x) {
+  double sum = 1.0, term = 1.0;
+  const double q = x * x / 4.0;
+  for (int k = 1; k < 200; ++k) {
+    term *= q / ((double)k * (double)k);
+    sum += term;
+    if (term < 1e-17 * sum) break;
+  }
+  return sum;
+}
+
+int pfb_design_prototype(uint32_t M, uint32_t P, double atten_db, float* taps) {
+  if (!taps || M == 0 || P == 0) return PFB_ERR_BAD_ARG;
+  const double pi = 3.14159265358979323846;
+  const int L = (int)(M * P);
+  double beta = 0.0;
+  if (atten_db > 50.0) beta = 0.1102 * (atten_db - 8.7);
+  else if (atten_db >= 21.0) beta = 0.5842 * std::pow(atten_db - 21.0, 0.4) + 0.07886 * (atten_db - 21.0);
+  const double i0b = bessel_i0(beta);
+  for (int n = 0; n < L; ++n) {
+    const double t = ((double)n - (double)L / 2.0) / (double)M;
+    const double s = (t == 0.0) ? 1.0 : std::sin(pi * t) / (pi * t);
+    const double r = 2.0 * (double)n / (double)L - 1.0;
+    const double w = bessel_i0(beta * std::sqrt(std::fmax(0.0, 1.0 - r * r))) / i0b;
+    taps[n] = (float)(s / (double)M * w);
+  }
+  return PFB_OK;
+}
+
+int pfb_create(const pfb_config* cfg, pfb_handle** out) {
+  if (!cfg || !out) return PFB_ERR_BAD_ARG;
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(pfb_config) || !cfg->taps) return PFB_ERR_BAD_ARG;
+  const uint32_t M = cfg->num_channels, P = cfg->taps_per_channel;
+  const uint32_t D = cfg->decimation ? cfg->decimation : M;
+  if (M < 2 || P < 1 || D < 1 || D > M) return PFB_ERR_BAD_ARG;
+  if (M > 4096 || P > 64) return PFB_ERR_UNSUPPORTED;
+  if (cfg->sample_format > PFB_FMT_CF32) return PFB_ERR_BAD_FORMAT;
+  if (cfg->output_layout > PFB_LAYOUT_CHANNEL_MAJOR) return PFB_ERR_BAD_ARG;
+  int bw = (int)cfg->bit_width;
+  if (cfg->sample_format == PFB_FMT_INT8_IQ && (bw < 1 || bw > 8)) return PFB_ERR_BAD_FORMAT;
+  if (cfg->sample_format == PFB_FMT_INT16_IQ && (bw < 1 || bw > 16)) return PFB_ERR_BAD_FORMAT;
+  if (cfg->sample_format == PFB_FMT_CF32) bw = 1;  // scale 1
+  const int off = cfg->input_offset < 0 ? (int)D - 1 : cfg->input_offset;
+  if (off >= (int)D) return PFB_ERR_BAD_ARG;
+
+  int ndev = 0;
+  const hipError_t ce = hipGetDeviceCount(&ndev);
+  if (ce != hipSuccess || ndev <= 0) {
+    g_detail = std::string("hipGetDeviceCount: ") + (ce == hipSuccess ? "0 devices" : hipGetErrorString(ce));
+    (void)hipGetLastError();
+    return PFB_ERR_NO_DEVICE;
+  }
+  int dev = cfg->device_id;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if (dev >= ndev) return PFB_ERR_BAD_ARG;
+
+  pfb_handle* h = new (std::nothrow) pfb_handle();
+  if (!h) return PFB_ERR_NO_MEMORY;
+  h->M = (int)M; h->P = (int)P; h->D = (int)D; h->off = off;
+  h->fmt = (int)cfg->sample_format; h->bit_width = bw; h->layout = (int)cfg->output_layout;
+  h->flags = cfg->flags;
+  h->device = dev;
+  h->bps = pfb::bytes_per_sample(h->fmt);
+  h->hist_samples = (int)(M * P + D);
+  h->fast = pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt);
+
+  DeviceGuard g(dev);
+  const size_t L = (size_t)M * P;
+  std::vector<float> taps(L);
+  const float scale = std::ldexp(1.0f, -(bw - 1));  // power of two: h*scale is exact
+  for (size_t i = 0; i < L; ++i) taps[i] = cfg->taps[i] * scale;
+  std::vector<float2> tw(M);
+  const double two_pi = 6.283185307179586476925286766559;
+  for (uint32_t m = 0; m < M; ++m) {
+    tw[m].x = (float)std::cos(two_pi * (double)m / (double)M);
+    tw[m].y = (float)std::sin(two_pi * (double)m / (double)M);
+  }
+  const size_t hist_bytes = (size_t)h->hist_samples * h->bps;
+  hipError_t e = hipMalloc((void**)&h->d_taps, L * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_tw, M * sizeof(float2));
+  if (e == hipSuccess) e = hipMalloc(&h->d_hist[0], hist_bytes);
+  if (e == hipSuccess) e = hipMalloc(&h->d_hist[1], hist_bytes);
+  if (e == hipSuccess) e = hipMemcpy(h->d_taps, taps.data(), L * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_tw, tw.data(), M * sizeof(float2), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(h->d_hist[0], 0, hist_bytes);
+  if (e == hipSuccess) e = hipMemset(h->d_hist[1], 0, hist_bytes);
+  if (e != hipSuccess) {
+    const int rc = hip_fail(e, "pfb_create allocation");
+    free_handle(h);
+    return rc;
+  }
+  *out = h;
+  return PFB_OK;
+}
+
+int pfb_destroy(pfb_handle* h) {
+  if (!h) return PFB_ERR_BAD_ARG;
+  free_handle(h);
+  return PFB_OK;
+}
+
+int pfb_reset(pfb_handle* h) {
+  if (!h) return PFB_ERR_BAD_ARG;
+  DeviceGuard g(h->device);
+  const size_t hist_bytes = (size_t)h->hist_samples * h->bps;
+  HIP_TRY(hipMemsetAsync(h->d_hist[h->cur], 0, hist_bytes, h->stream));
+  h->phase = 0;
+  h->frame_index = 0;
+  return PFB_OK;
+}
+
+int pfb_set_stream(pfb_handle* h, void* hip_stream) {
+  if (!h) return PFB_ERR_BAD_ARG;
+  h->stream = static_cast<hipStream_t>(hip_stream);
+  return PFB_OK;
+}
+
+int pfb_frames_for(const pfb_handle* h, uint64_t n, uint64_t* frames_out) {
+  if (!h || !frames_out) return PFB_ERR_BAD_ARG;
+  *frames_out = frames_for(h, n);
+  return PFB_OK;
+}
+
+int pfb_process_async(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t cap,
+                      uint64_t* frames_out) {
+  if (!h || (n > 0 && !d_iq)) return PFB_ERR_BAD_ARG;
+  const uint64_t f = frames_for(h, n);
+  if (frames_out) *frames_out = f;
+  if (f > cap) return PFB_ERR_CAPACITY;
+  if (f > 0 && !d_out) return PFB_ERR_BAD_ARG;
+  DeviceGuard g(h->device);
+  return enqueue(h, d_iq, n, d_out, f, (int64_t)f, 0);
+}
+
+int pfb_sync(pfb_handle* h) {
+  if (!h) return PFB_ERR_BAD_ARG;
+  DeviceGuard g(h->device);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return PFB_OK;
+}
+
+int pfb_process(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t cap, uint64_t* frames_out,
+                uint32_t mem) {
+  if (!h || (n > 0 && !iq) || mem > PFB_MEM_DEVICE) return PFB_ERR_BAD_ARG;
+  const uint64_t f = frames_for(h, n);
+  if (frames_out) *frames_out = f;
+  if (f > cap) return PFB_ERR_CAPACITY;
+  if (f > 0 && !out) return PFB_ERR_BAD_ARG;
+  DeviceGuard g(h->device);
+  if (mem == PFB_MEM_DEVICE) {
+    const int rc = enqueue(h, iq, n, out, f, (int64_t)f, 0);
+    if (rc != PFB_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PFB_OK;
+  }
+  return process_host(h, iq, n, out, f);
+}
+
+uint64_t pfb_history_samples(const pfb_handle* h) { return h ? (uint64_t)h->hist_samples : 0; }
+
+int pfb_prime(pfb_handle* h, const void* iq, uint64_t n, uint32_t mem) {
+  if (!h || (n > 0 && !iq) || mem > PFB_MEM_DEVICE) return PFB_ERR_BAD_ARG;
+  if (n == 0) return PFB_OK;
+  DeviceGuard g(h->device);
+  const uint64_t f = frames_for(h, n);
+  // only the trailing hist_samples matter
+  const uint64_t keep = std::min<uint64_t>(n, (uint64_t)h->hist_samples);
+  const char* tail = static_cast<const char*>(iq) + (n - keep) * h->bps;
+  const void* d_tail = tail;
+  if (mem == PFB_MEM_HOST) {
+    const int rc = ensure_stage(h, (size_t)keep * h->bps, 0);
+    if (rc != PFB_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_stage_in, tail, (size_t)keep * h->bps, hipMemcpyHostToDevice, h->stream));
+    d_tail = h->d_stage_in;
+  }
+  HIP_TRY(pfb::launch_update_history(h->d_hist[h->cur], d_tail, (long long)keep, h->d_hist[h->cur ^ 1],
+                                     h->hist_samples, h->bps, h->stream));
+  h->cur ^= 1;
+  h->phase = (uint32_t)((h->phase + n) % (uint64_t)h->D);
+  h->frame_index += f;
+  if (mem == PFB_MEM_HOST) HIP_TRY(hipStreamSynchronize(h->stream));
+  return PFB_OK;
+}
+
+int pfb_get_state(pfb_handle* h, void* buf, size_t* bytes) {
+  if (!h || !bytes) return PFB_ERR_BAD_ARG;
+  const size_t hist_bytes = (size_t)h->hist_samples * h->bps;
+  const size_t need = sizeof(StateHeader) + hist_bytes;
+  if (!buf) { *bytes = need; return PFB_OK; }
+  if (*bytes < need) { *bytes = need; return PFB_ERR_CAPACITY; }
+  DeviceGuard g(h->device);
+  StateHeader sh{kStateMagic, (uint32_t)h->M, (uint32_t)h->P, (uint32_t)h->D, (uint32_t)h->fmt,
+                 (uint32_t)h->hist_samples, h->phase, 0u, h->frame_index};
+  std::memcpy(buf, &sh, sizeof(sh));
+  HIP_TRY(hipMemcpyAsync(static_cast<char*>(buf) + sizeof(sh), h->d_hist[h->cur], hist_bytes, hipMemcpyDeviceToHost,
+                         h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *bytes = need;
+  return PFB_OK;
+}
+
+int pfb_set_state(pfb_handle* h, const void* buf, size_t bytes) {
+  if (!h || !buf || bytes < sizeof(StateHeader)) return PFB_ERR_BAD_ARG;
+  StateHeader sh;
+  std::memcpy(&sh, buf, sizeof(sh));
+  const size_t hist_bytes = (size_t)h->hist_samples * h->bps;
+  if (sh.magic != kStateMagic || sh.M != (uint32_t)h->M || sh.P != (uint32_t)h->P || sh.D != (uint32_t)h->D ||
+      sh.fmt != (uint32_t)h->fmt || sh.hist_samples != (uint32_t)h->hist_samples || sh.phase >= (uint32_t)h->D ||
+      bytes < sizeof(sh) + hist_bytes)
+    return PFB_ERR_BAD_ARG;
+  DeviceGuard g(h->device);
+  HIP_TRY(hipMemcpyAsync(h->d_hist[h->cur], static_cast<const char*>(buf) + sizeof(sh), hist_bytes,
+                         hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->phase = sh.phase;
+  h->frame_index = sh.frame_index;
+  return PFB_OK;
+}
+
+int pfb_set_frame_index(pfb_handle* h, uint64_t next_frame) {
+  if (!h) return PFB_ERR_BAD_ARG;
+  h->frame_index = next_frame;
+  return PFB_OK;
+}
+
+int pfb_get_frame_index(const pfb_handle* h, uint64_t* next_frame) {
+  if (!h || !next_frame) return PFB_ERR_BAD_ARG;
+  *next_frame = h->frame_index;
+  return PFB_OK;
+}
+
+int pfb_set_option(pfb_handle* h, int option, int64_t value) {
+  if (!h) return PFB_ERR_BAD_ARG;
+  switch (option) {
+    case PFB_OPT_KERNEL:
+      if (value < 0 || value > 2) return PFB_ERR_BAD_ARG;
+      h->opt_kernel = (int)value;
+      return PFB_OK;
+    case PFB_OPT_FRAMES_PER_BLOCK:
+      if (value < 0 || value > (1 << 24)) return PFB_ERR_BAD_ARG;
+      h->opt_frames_per_block = (int)value;
+      return PFB_OK;
+    case PFB_OPT_HOST_CHUNK_SAMPLES:
+      if (value < 0) return PFB_ERR_BAD_ARG;
+      h->opt_host_chunk = value;
+      return PFB_OK;
+    case PFB_OPT_NONTEMPORAL:
+      h->opt_nontemporal = value ? 1 : 0;
+      return PFB_OK;
+    case PFB_OPT_PROFILE:
+      h->opt_profile = value ? 1 : 0;
+      h->ev_used = 0;
+      return PFB_OK;
+    default:
+      return PFB_ERR_BAD_ARG;
+  }
+}
+
+const char* pfb_last_kernel(const pfb_handle* h) { return h ? h->last_kernel : ""; }
+
+int pfb_get_kernel_times(pfb_handle* h, float* ms_out, int capacity, int* count) {
+  if (!h || !count || (capacity > 0 && !ms_out)) return PFB_ERR_BAD_ARG;
+  DeviceGuard g(h->device);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int n = 0;
+  for (size_t i = 0; i < h->ev_used && n < capacity; ++i, ++n)
+    HIP_TRY(hipEventElapsedTime(&ms_out[n], h->ev_pool[i].first, h->ev_pool[i].second));
+  h->ev_used = 0;
+  *count = n;
+  return PFB_OK;
+}
+
+int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double* bytes_per_sec) {
+  if (!bytes_per_sec || iters < 1 || bytes_in < 16) return PFB_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return PFB_ERR_NO_DEVICE;
+  }
+  int dev = device_id;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  DeviceGuard g(dev);
+  const long long nvec = (long long)(bytes_in / 16);
+  void *in = nullptr, *out = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = PFB_OK;
+  float ms = 0.f;
+  hipError_t e = hipMalloc(&in, (size_t)nvec * 16);
+  if (e == hipSuccess) e = hipMalloc(&out, (size_t)nvec * 32);
+  if (e == hipSuccess) e = hipMemset(in, 1, (size_t)nvec * 16);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = pfb::launch_stream_copy(in, out, nvec, nullptr);  // warm-up
+  if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+  for (int i = 0; i < iters && e == hipSuccess; ++i) e = pfb::launch_stream_copy(in, out, nvec, nullptr);
+  if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (e != hipSuccess) rc = hip_fail(e, "pfb_measure_stream_copy");
+  else *bytes_per_sec = (double)nvec * 48.0 * iters / ((double)ms * 1e-3);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(in);
+  (void)hipFree(out);
+  return rc;
+}
+
+}  // extern "C"

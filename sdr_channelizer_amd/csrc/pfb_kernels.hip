@@ -1,0 +1,213 @@
+// pfb_kernels.hip -- gfx950 kernels of the channelizer library and their launchers.
+//
+//   pfb_fast_kernel<...>   the hot path (pfb_fast.hpp), one instantiation per
+//                          (M, P, D, sample format) in kFastTable below
+//   pfb_generic_kernel     any M (2^k by radix-2 in LDS, otherwise a plain DFT),
+//                          any P, any 1 <= D <= M, any format / layout: the
+//                          correctness net for configurations without a fast
+//                          instantiation (e.g. the reference's own M = fs*1e-6 = 56,
+//                          /root/reference/matlab/channelizer_example.m:29)
+//   pfb_update_history     carries the last M*P + D raw samples to the next call
+//                          (the dsp.Channelizer System-object state,
+//                          channelizer_example.m:50-56)
+//   pfb_stream_copy        1 read : 2 write streaming copy, the measured-HBM yardstick
+#include "pfb_fast.hpp"
+
+namespace pfb {
+
+// ---------------------------------------------------------------------------------
+// generic kernel
+
+__device__ __forceinline__ void fetch_sample(const KernelParams& p, long long s, float& re, float& im) {
+  const void* b;
+  long long i;
+  if (s >= 0) { b = p.in; i = s; } else { b = p.hist; i = p.hist_samples + s; }
+  if (p.fmt == PFB_FMT_INT16_IQ) {
+    SampleT<PFB_FMT_INT16_IQ>::cvt(static_cast<const uint32_t*>(b)[i], re, im);
+  } else if (p.fmt == PFB_FMT_INT8_IQ) {
+    SampleT<PFB_FMT_INT8_IQ>::cvt(static_cast<const uint16_t*>(b)[i], re, im);
+  } else {
+    SampleT<PFB_FMT_CF32>::cvt(static_cast<const float2*>(b)[i], re, im);
+  }
+}
+
+__device__ __forceinline__ int bit_reverse(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
+
+// tile_frames frames per workgroup; sm holds tile_frames*M complex (x2 when M is not 2^k)
+__global__ void __launch_bounds__(256) pfb_generic_kernel(const KernelParams p, int tile_frames, int log2m) {
+  extern __shared__ float2 sm[];
+  const int M = p.M, P = p.P, D = p.D;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const long long f0 = (long long)blockIdx.x * tile_frames;
+  const int eff_off = p.base + D - 1;
+  const float im_sign = (p.flags & PFB_FLAG_CONJUGATE_INPUT) ? -1.f : 1.f;
+
+  // polyphase branches u_p[f] = sum_q h[p + Mq] x[f D + eff_off - p - Mq]
+  for (int idx = tid; idx < tile_frames * M; idx += nt) {
+    const int t = idx / M, br = idx - t * M;
+    const long long f = f0 + t;
+    float ar = 0.f, ai = 0.f;
+    if (f < p.frames) {
+      for (int q = 0; q < P; ++q) {
+        float xr, xi;
+        fetch_sample(p, f * D + eff_off - br - (long long)M * q, xr, xi);
+        const float hq = p.taps[br + M * q];
+        ar = fmaf(hq, xr, ar);
+        ai = fmaf(hq, xi, ai);
+      }
+    }
+    const int pos = (log2m >= 0) ? bit_reverse(br, log2m) : br;
+    sm[t * M + pos] = make_float2(ar, ai * im_sign);
+  }
+  __syncthreads();
+
+  if (log2m >= 0) {  // radix-2 DIT, e^{+j} kernel, in place
+    for (int len = 2; len <= M; len <<= 1) {
+      const int half = len >> 1, step = M / len;
+      for (int idx = tid; idx < tile_frames * (M / 2); idx += nt) {
+        const int t = idx / (M / 2), b = idx - t * (M / 2);
+        const int j = b % half, i = (b / half) * len + j;
+        const float2 w = p.tw[j * step];
+        float2* a = &sm[t * M + i];
+        const float2 lo = a[0], hi = a[half];
+        const float br_ = hi.x * w.x - hi.y * w.y, bi_ = hi.x * w.y + hi.y * w.x;
+        a[0] = make_float2(lo.x + br_, lo.y + bi_);
+        a[half] = make_float2(lo.x - br_, lo.y - bi_);
+      }
+      __syncthreads();
+    }
+  } else {  // plain DFT into the second half of sm
+    float2* y = sm + tile_frames * M;
+    for (int idx = tid; idx < tile_frames * M; idx += nt) {
+      const int t = idx / M, k = idx - t * M;
+      float ar = 0.f, ai = 0.f;
+      int j = 0;  // (k*p) mod M, advanced incrementally
+      for (int pp = 0; pp < M; ++pp) {
+        const float2 u = sm[t * M + pp], w = p.tw[j];
+        ar += u.x * w.x - u.y * w.y;
+        ai += u.x * w.y + u.y * w.x;
+        j += k; if (j >= M) j -= M;
+      }
+      y[idx] = make_float2(ar, ai);
+    }
+    __syncthreads();
+  }
+
+  const float2* y = (log2m >= 0) ? sm : sm + tile_frames * M;
+  const int half_shift = M / 2;  // fftshift(out,2): dst = (k + floor(M/2)) mod M
+  if (p.layout == PFB_LAYOUT_FRAME_MAJOR) {
+    for (int idx = tid; idx < tile_frames * M; idx += nt) {
+      const int t = idx / M, k = idx - t * M;
+      const long long f = f0 + t;
+      if (f >= p.frames) continue;
+      float2 v = y[idx];
+      if (p.flags & PFB_FLAG_DEROTATE) {
+        const long long rot = ((p.frame0 + f) * D) % M;
+        const float2 w = p.tw[(int)(((long long)k * rot) % M)];
+        v = make_float2(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y);  // * conj(w)
+      }
+      const int col = (p.flags & PFB_FLAG_FFTSHIFT) ? (k + half_shift) % M : k;
+      p.out[f * M + col] = v;
+    }
+  } else {  // CHANNEL_MAJOR: consecutive threads write consecutive frames of one channel
+    for (int idx = tid; idx < tile_frames * M; idx += nt) {
+      const int k = idx / tile_frames, t = idx - k * tile_frames;
+      const long long f = f0 + t;
+      if (f >= p.frames) continue;
+      float2 v = y[t * M + k];
+      if (p.flags & PFB_FLAG_DEROTATE) {
+        const long long rot = ((p.frame0 + f) * D) % M;
+        const float2 w = p.tw[(int)(((long long)k * rot) % M)];
+        v = make_float2(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y);
+      }
+      const int col = (p.flags & PFB_FLAG_FFTSHIFT) ? (k + half_shift) % M : k;
+      p.out[(long long)col * p.out_ld + p.out_frame0 + f] = v;
+    }
+  }
+}
+
+hipError_t launch_generic(const KernelParams& p, hipStream_t s) {
+  if (p.frames <= 0) return hipSuccess;
+  const int M = p.M;
+  int log2m = -1;
+  if ((M & (M - 1)) == 0) { log2m = 0; while ((1 << log2m) < M) ++log2m; }
+  int tile = 4096 / M;
+  if (tile < 1) tile = 1;
+  if (tile > 16) tile = 16;
+  const size_t shmem = (size_t)tile * M * sizeof(float2) * (log2m >= 0 ? 1 : 2);
+  if (shmem > 64 * 1024) return hipErrorInvalidValue;
+  const long long blocks = (p.frames + tile - 1) / tile;
+  hipLaunchKernelGGL(pfb_generic_kernel, dim3((unsigned)blocks), dim3(256), shmem, s, p, tile, log2m);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// history update: new[i] = stream[n_in - H + i], stream = [old history | in]
+
+template <typename T>
+__global__ void pfb_update_history_kernel(const T* old_hist, const T* in, long long n_in, T* new_hist, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H) return;
+  const long long s = n_in - H + i;
+  new_hist[i] = (s >= 0) ? in[s] : old_hist[H + s];
+}
+
+hipError_t launch_update_history(const void* old_hist, const void* in, long long n_in, void* new_hist,
+                                 int hist_samples, int bps, hipStream_t s) {
+  const dim3 grid((hist_samples + 255) / 256), block(256);
+  if (bps == 2)
+    hipLaunchKernelGGL(pfb_update_history_kernel<uint16_t>, grid, block, 0, s, (const uint16_t*)old_hist,
+                       (const uint16_t*)in, n_in, (uint16_t*)new_hist, hist_samples);
+  else if (bps == 4)
+    hipLaunchKernelGGL(pfb_update_history_kernel<uint32_t>, grid, block, 0, s, (const uint32_t*)old_hist,
+                       (const uint32_t*)in, n_in, (uint32_t*)new_hist, hist_samples);
+  else
+    hipLaunchKernelGGL(pfb_update_history_kernel<uint64_t>, grid, block, 0, s, (const uint64_t*)old_hist,
+                       (const uint64_t*)in, n_in, (uint64_t*)new_hist, hist_samples);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// 1 read : 2 write streaming copy (same byte mix as int16 -> complex64, D = M)
+
+__global__ void __launch_bounds__(256) pfb_stream_copy_kernel(const uint4* in, uint4* out, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint4 v = in[i];
+    out[i] = v;
+    out[n + i] = v;
+  }
+}
+
+hipError_t launch_stream_copy(const void* in, void* out, long long n_vec16, hipStream_t s) {
+  hipLaunchKernelGGL(pfb_stream_copy_kernel, dim3(256 * 8), dim3(256), 0, s, (const uint4*)in, (uint4*)out, n_vec16);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// fast kernel table
+//                 M    P   D  CPT FMT               C NP R0 R1 R2 RS0 RS1 RS2 FS  PP     MINW
+using Cfg64x12i16 = FastCfg<64, 12, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
+using Cfg64x12i8  = FastCfg<64, 12, 64, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
+using Cfg64x12f32 = FastCfg<64, 12, 64, 1, PFB_FMT_CF32,     8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
+
+struct FastEntry { int M, P, D, fmt; FastKernelInfo info; };
+
+template <class K>
+constexpr FastEntry entry(const char* name, int default_fpb) {
+  return FastEntry{K::M, K::P, K::D, K::FMT, FastKernelInfo{&launch_fast<K>, name, K::C, default_fpb, K::CPT}};
+}
+
+static const FastEntry kFastTable[] = {
+    entry<Cfg64x12i16>("pfb_fast<M64,P12,D64,int16>", 512),
+    entry<Cfg64x12i8>("pfb_fast<M64,P12,D64,int8>", 512),
+    entry<Cfg64x12f32>("pfb_fast<M64,P12,D64,cf32>", 512),
+};
+
+const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt) {
+  for (const FastEntry& e : kFastTable)
+    if (e.M == M && e.P == P && e.D == D && e.fmt == fmt) return &e.info;
+  return nullptr;
+}
+
+}  // namespace pfb

@@ -1,0 +1,71 @@
+"""Time-sharding the stream across GPUs.
+
+Frames only depend on the M*P - 1 samples before them, so G ranks each take one
+contiguous segment (a multiple of D samples) and the only exchange is the *halo*: the
+last ``history_samples`` raw integer samples of segment g become the filter state of
+segment g+1.  The sharded output is bit-identical to the single-stream output because the
+halo is raw input, not a partial result.  One process per GPU; the transport is
+``torch.distributed`` point-to-point (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  Message size is tiny (61 KB at M=1024, P=16), so this is
+latency- not bandwidth-bound.
+"""
+from __future__ import annotations
+
+
+def segment_bounds(total_samples: int, world: int, decimation: int) -> list[tuple[int, int]]:
+    """Cut [0, total) into `world` contiguous segments on frame boundaries (multiples of D)."""
+    frames = total_samples // decimation
+    per = [frames // world + (1 if r < frames % world else 0) for r in range(world)]
+    bounds, s = [], 0
+    for r in range(world):
+        e = s + per[r] * decimation
+        bounds.append((s, e))
+        s = e
+    return bounds
+
+
+def exchange_halo(tail, halo_out, rank: int, world: int, group=None, ring: bool = True):
+    """Send ``tail`` (my segment's last history_samples samples) to rank+1 and receive the
+    previous rank's into ``halo_out``.  With ring=False rank 0 receives nothing (stream start:
+    its state stays as it is) and the last rank sends nothing."""
+    import torch.distributed as dist
+    if world == 1:
+        return halo_out
+    ops = []
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
+    if ring or rank + 1 < world:
+        ops.append(dist.P2POp(dist.isend, tail, nxt, group))
+    if ring or rank > 0:
+        ops.append(dist.P2POp(dist.irecv, halo_out, prv, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return halo_out
+
+
+class ShardedChannelizer:
+    """One rank's view of a time-sharded channelizer run.
+
+    >>> sc = ShardedChannelizer(ch, rank, world)          # ch: a Channelizer on this rank's GPU
+    >>> y_local = sc.process_segment(my_segment_tensor)   # frames of my segment only
+    """
+
+    def __init__(self, channelizer, rank: int, world: int, group=None):
+        self.ch, self.rank, self.world, self.group = channelizer, rank, world, group
+
+    def process_segment(self, segment, first_frame: int = 0, out=None):
+        """``segment``: this rank's contiguous slice (device tensor, length a multiple of D).
+        ``first_frame``: global index of the segment's first frame (only matters for derotate)."""
+        import torch
+        hist = self.ch.history_samples
+        self.ch.reset()
+        if self.world > 1:
+            if segment.shape[0] < hist:
+                raise ValueError("segment shorter than the halo")
+            halo = torch.empty((hist,) + tuple(segment.shape[1:]), dtype=segment.dtype, device=segment.device)
+            exchange_halo(segment[segment.shape[0] - hist:].contiguous(), halo, self.rank, self.world, self.group,
+                          ring=False)
+            if self.rank > 0:
+                self.ch.prime(halo)
+        self.ch.set_frame_index(first_frame)
+        return self.ch(segment, out=out)

@@ -1,0 +1,87 @@
+"""The C-ABI library without a GPU: it loads, exports every symbol the headers declare,
+the pure-host helpers work, and compute entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sdr_channelizer_amd as pkg
+from sdr_channelizer_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for hdr in ("pfb_channelizer.h", "pfb_iq_packet.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(pfb_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    declared = declared_symbols()
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pfb_abi_version() == 1
+
+
+def test_strerror_and_center_frequencies(oracle):
+    lib = L.load()
+    assert lib.pfb_strerror(0) == b"ok" and lib.pfb_strerror(L.PFB_ERR_NO_DEVICE) == b"no HIP device"
+    for M, fs in ((8, 8e6), (56, 56e6), (5, 5.0)):
+        assert np.array_equal(pkg.center_frequencies(M, fs), oracle.center_frequencies(M, fs))
+
+
+def test_prototype_matches_oracle_design(oracle):
+    for M, P in ((8, 12), (64, 12), (256, 8)):
+        assert np.allclose(pkg.design_prototype(M, P), oracle.design_prototype(M, P), rtol=0, atol=2e-8)
+
+
+def test_create_validates_arguments():
+    lib = L.load()
+    h = C.c_void_p()
+    taps = np.zeros(64 * 12, np.float32)
+    tp = taps.ctypes.data_as(C.POINTER(C.c_float))
+
+    def cfg(**kw):
+        d = dict(struct_size=C.sizeof(L.PfbConfig), num_channels=64, taps_per_channel=12, decimation=0, taps=tp,
+                 sample_format=L.PFB_FMT_INT16_IQ, bit_width=12, output_layout=0, flags=0, input_offset=-1,
+                 device_id=-1)
+        d.update(kw)
+        return L.PfbConfig(**d)
+
+    assert lib.pfb_create(None, C.byref(h)) == L.PFB_ERR_BAD_ARG
+    assert lib.pfb_create(C.byref(cfg(struct_size=8)), C.byref(h)) == L.PFB_ERR_BAD_ARG
+    assert lib.pfb_create(C.byref(cfg(num_channels=1)), C.byref(h)) == L.PFB_ERR_BAD_ARG
+    assert lib.pfb_create(C.byref(cfg(decimation=65)), C.byref(h)) == L.PFB_ERR_BAD_ARG
+    assert lib.pfb_create(C.byref(cfg(input_offset=64)), C.byref(h)) == L.PFB_ERR_BAD_ARG
+    assert lib.pfb_create(C.byref(cfg(sample_format=7)), C.byref(h)) == L.PFB_ERR_BAD_FORMAT
+    assert lib.pfb_create(C.byref(cfg(sample_format=L.PFB_FMT_INT8_IQ, bit_width=12)), C.byref(h)) == L.PFB_ERR_BAD_FORMAT
+    assert lib.pfb_process(None, None, 0, None, 0, None, 0) == L.PFB_ERR_BAD_ARG
+
+
+def test_no_cpu_fallback():
+    """On a box without a HIP device the product refuses to compute instead of falling back."""
+    lib = L.load()
+    if lib.pfb_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.PfbError) as e:
+        pkg.Channelizer(64)
+    assert e.value.status == L.PFB_ERR_NO_DEVICE
+    r = C.c_double()
+    assert lib.pfb_measure_stream_copy(-1, 1 << 20, 1, C.byref(r)) == L.PFB_ERR_NO_DEVICE
+
+
+def test_product_sources_do_not_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package may import, link or call it."""
+    for base, _, files in os.walk(os.path.join(ROOT, "sdr_channelizer_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".c")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "pfb_oracle" not in text and "pfbo_" not in text and "from oracle" not in text, f

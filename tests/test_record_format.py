@@ -1,0 +1,111 @@
+"""The .iq record format: our restatements (include/pfb_iq_packet.h via libpfb_channelizer.so,
+oracle/pfb_oracle.c, sdr_channelizer_amd/iqfile.py) pinned against the reference's own
+cpp/IqPacket.h + cpp/Helper.cpp compiled into oracle/_ref."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle.pfb_oracle import RefIqPacket
+from sdr_channelizer_amd import _lib as L
+from sdr_channelizer_amd import iqfile
+
+needs_ref = pytest.mark.skipif(not RefIqPacket.available(), reason="oracle/_ref not built")
+
+EXPECTED_OFFSETS = dict(endianness=0, linkSpeed=4, frequencyHz=8, bandwidthHz=16, sampleRateSps=20, rxGainDb=24,
+                        numSamples=28, bitWidth=32, spare0=36, boardName=40, serialNumber=56, fpgaVersion=72,
+                        fwVersion=88, sampleStartTime=104)
+
+
+def test_our_struct_layout():
+    assert C.sizeof(L.PfbIqPacket) == 112
+    for name, off in EXPECTED_OFFSETS.items():
+        assert getattr(L.PfbIqPacket, name).offset == off, name
+
+
+@needs_ref
+def test_layout_matches_reference_build():
+    ref = RefIqPacket()
+    assert ref.sizeof() == C.sizeof(L.PfbIqPacket) == 112
+    assert ref.offsets() == EXPECTED_OFFSETS
+
+
+@needs_ref
+@pytest.mark.parametrize("marker,bw", [(0x02020202, 12), (0x03030303, 16), (0x03030303, 8), (0x02020202, 8)])
+def test_parse_reference_written_header(oracle, marker, bw):
+    ref = RefIqPacket()
+    raw = ref.make_header(marker, 5000, 2_412_000_000, 56_000_000, 56_000_000, 31.5, 123456, bw,
+                          b"bladerf", b"0123456789abcde", b"v0.15.0", b"v2.4.0", 1.7e9 + 0.25)
+    assert len(raw) == 112
+    info = iqfile.parse_header(raw)
+    p = info.packet
+    assert (p.endianness, p.linkSpeed, p.frequencyHz, p.bandwidthHz, p.sampleRateSps) == \
+        (marker, 5000, 2_412_000_000, 56_000_000, 56_000_000)
+    assert (p.numSamples, p.bitWidth, p.sampleStartTime) == (123456, bw, 1.7e9 + 0.25)
+    assert p.boardName == b"bladerf" and p.serialNumber == b"0123456789abcde"
+    assert info.header_bytes == 112 and info.file_format == (2 if marker == 0x02020202 else 3)
+    assert info.bytes_per_sample == (2 if bw <= 8 else 4)
+    # convert_my_iq_to_mat.m:73-77 reads the gain word as uint32 unless fmt >= 3 (bladeRF quirk kept)
+    want_gain = 31.5 if marker == 0x03030303 else float(np.float32(31.5).view(np.uint32))
+    assert info.rx_gain_as_read == want_gain
+    o = oracle.parse_iq_header(raw)  # the oracle's own parser agrees field by field
+    assert o["frequency_hz"] == p.frequencyHz and o["num_samples"] == p.numSamples
+    assert o["rx_gain_db"] == want_gain and o["header_bytes"] == 112 and o["bytes_per_sample"] == info.bytes_per_sample
+
+
+def test_parse_fmt1_header_as_generate_training_iq_writes_it(oracle):
+    """matlab/generate_training_iq.m:109-123: 8 x uint32, 64 bytes of strings, one double = 104 bytes."""
+    words = np.array([0x01010101, 1, 0, 56_000_000, 56_000_000, 0, 5_600_000, 16], dtype="<u4").tobytes()
+    strings = b"simulated" + bytes(64 - 9)
+    raw = words + strings + np.array([1.6e9], dtype="<f8").tobytes()
+    assert len(raw) == 104
+    info = iqfile.parse_header(raw)
+    assert info.file_format == 1 and info.header_bytes == 104 and info.bytes_per_sample == 4
+    assert info.packet.sampleRateSps == 56_000_000 and info.packet.numSamples == 5_600_000
+    assert info.packet.bitWidth == 16 and info.packet.boardName == b"simulated"
+    assert info.packet.sampleStartTime == 1.6e9
+    assert oracle.parse_iq_header(raw)["header_bytes"] == 104
+
+
+def test_bad_headers_are_rejected():
+    lib = L.load()
+    info = L.PfbIqInfo()
+    bad = np.array([0xdeadbeef] + [0] * 27, dtype="<u4").tobytes()
+    assert lib.pfb_iq_parse_header(bad, len(bad), C.byref(info)) == L.PFB_ERR_BAD_FORMAT
+    big_endian = bytes(112)  # marker 0x00000000: convert_my_iq_to_mat.m:43 "big endian"; no writer emits it
+    assert lib.pfb_iq_parse_header(big_endian, 112, C.byref(info)) == L.PFB_ERR_BAD_FORMAT
+    short = np.array([0x03030303], dtype="<u4").tobytes() + bytes(20)
+    assert lib.pfb_iq_parse_header(short, len(short), C.byref(info)) == L.PFB_ERR_BAD_ARG
+    hdr = bytearray(112)
+    hdr[0:4] = (0x03030303).to_bytes(4, "little")
+    hdr[32:36] = (24).to_bytes(4, "little")  # bitWidth 24: "Unsupported bit width" (:96-98)
+    assert lib.pfb_iq_parse_header(bytes(hdr), 112, C.byref(info)) == L.PFB_ERR_BAD_FORMAT
+
+
+@needs_ref
+@pytest.mark.parametrize("ms", [0, 1_700_000_000_123, 951_782_400_000, 1_709_251_199_999])
+def test_filename_matches_reference_helper(ms):
+    assert iqfile.filename_for(ms) == RefIqPacket().filename(ms)
+
+
+def test_record_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    for dt, bw in ((np.int16, 12), (np.int8, 8), (np.int16, 16)):
+        iq = rng.integers(-100, 100, size=(1000, 2)).astype(dt)
+        path = os.path.join(tmp_path, f"r{bw}.iq")
+        iqfile.write_iq(path, iq, fs=56e6, fc=2.4e9, bit_width=bw, gain_db=30.0, start_time=123.5)
+        r = iqfile.read_iq(path)
+        assert np.array_equal(r.iq, iq) and r.iq.dtype == dt
+        assert (r.fs, r.fc, r.bitWidth, r.sampleStartTime, r.gain, r.fileFormat) == (56e6, 2.4e9, bw, 123.5, 30.0, 3)
+        assert os.path.getsize(path) == 112 + iq.nbytes  # header then (n)*sizeof(complex<intX>) (:321-322)
+
+
+@needs_ref
+def test_our_writer_emits_the_reference_bytes(tmp_path):
+    ref = RefIqPacket().make_header(0x03030303, 0, 915_000_000, 20_000_000, 20_000_000, 12.0, 10, 16,
+                                    b"usrp", b"s1", b"", b"", 99.0)
+    path = os.path.join(tmp_path, "w.iq")
+    iqfile.write_iq(path, np.zeros((10, 2), np.int16), fs=20e6, fc=915e6, bit_width=16, gain_db=12.0,
+                    start_time=99.0, board="usrp", serial="s1")
+    assert open(path, "rb").read()[:112] == ref

@@ -1,0 +1,120 @@
+"""Index-level model of the multi-pass LDS FFT used by the fast kernels
+(sdr_channelizer_amd/csrc/pfb_fast.hpp).  Executable documentation: it checks
+the position / twiddle formulas against numpy.fft for every plan the kernels
+instantiate, and reports LDS bank conflicts of each pass under the MI355X
+banking rules (ds_read_b64: 2x32-lane groups, 64 banks; ds_write_b64: 4x16-lane
+groups, 32 banks).
+
+Plan R = [R0..R_{n-1}], M = prod(R).  S_i = prod(R[i+1:]), K_i = prod(R[:i]).
+Input of pass i lives at pos_i(n_i, item) = n_i*RS_i + item, item = kk*S_i + rest.
+"""
+import itertools
+import sys
+import numpy as np
+
+
+def strides(R):
+    n = len(R)
+    S = [int(np.prod(R[i + 1:])) for i in range(n)]
+    K = [int(np.prod(R[:i])) for i in range(n)]
+    return S, K
+
+
+def run_plan(x, R, RS):
+    """x: (M,) complex in natural order. Returns y[k] = sum_n x[n] e^{+2 pi j n k / M}."""
+    M = x.size
+    S, K = strides(R)
+    FS = max(R[i] * RS[i] for i in range(len(R)))
+    buf = np.zeros(FS, dtype=complex)
+    # FIR writes element n at pos_0
+    for n in range(M):
+        n0, rest = divmod(n, S[0])
+        buf[n0 * RS[0] + rest] = x[n]
+    out = np.zeros(M, dtype=complex)
+    for i, Ri in enumerate(R):
+        nxt = np.zeros_like(buf)
+        for item in range(M // Ri):
+            kk, rest = divmod(item, S[i])
+            a = np.array([buf[n * RS[i] + item] for n in range(Ri)])
+            b = np.array([sum(a[n] * np.exp(2j * np.pi * n * k / Ri) for n in range(Ri)) for k in range(Ri)])
+            if i + 1 < len(R):
+                b = b * np.exp(2j * np.pi * rest * np.arange(Ri) / (Ri * S[i]))
+                n1, rest2 = divmod(rest, S[i + 1])
+                for k in range(Ri):
+                    item2 = (kk + k * K[i]) * S[i + 1] + rest2
+                    nxt[n1 * RS[i + 1] + item2] = b[k]
+            else:
+                for k in range(Ri):
+                    out[kk + k * K[i]] = b[k]
+        buf = nxt
+    return out
+
+
+def conflicts(addrs_by_lane, kind):
+    """addrs_by_lane: list of 64 element addresses (8-byte units) or None for idle lanes.
+    Returns worst-case serialisation factor over the lane groups."""
+    if kind == "read":   # ds_read_b64
+        groups, nb = [range(0, 32), range(32, 64)], 64
+    else:                # ds_write_b64
+        groups, nb = [range(g * 16, g * 16 + 16) for g in range(4)], 32
+    worst = 1
+    for g in groups:
+        per_bank = {}
+        for l in g:
+            a = addrs_by_lane[l]
+            if a is None:
+                continue
+            for d in (0, 1):
+                bank = (2 * a + d) % nb
+                per_bank.setdefault(bank, set()).add(2 * a + d)
+        if per_bank:
+            worst = max(worst, max(len(s) for s in per_bank.values()))
+    return worst
+
+
+def check_conflicts(M, R, RS, FS, C, NT):
+    S, K = strides(R)
+    rep = []
+    for i, Ri in enumerate(R):
+        ipf = M // Ri
+        items = C * ipf
+        for it in range((items + NT - 1) // NT):
+            for wave in range(NT // 64):
+                lanes = [wave * 64 + l + it * NT for l in range(64)]
+                for n in range(Ri):
+                    ad = [None if w >= items else (w // ipf) * FS + n * RS[i] + (w % ipf) for w in lanes]
+                    c = conflicts(ad, "read")
+                    if c > 1:
+                        rep.append((f"pass{i} read n={n}", c))
+                if i + 1 < len(R):
+                    for k in range(Ri):
+                        ad = []
+                        for w in lanes:
+                            if w >= items:
+                                ad.append(None); continue
+                            fc, item = divmod(w, ipf)
+                            kk, rest = divmod(item, S[i])
+                            n1, rest2 = divmod(rest, S[i + 1])
+                            item2 = (kk + k * K[i]) * S[i + 1] + rest2
+                            ad.append(fc * FS + n1 * RS[i + 1] + item2)
+                        c = conflicts(ad, "write")
+                        if c > 1:
+                            rep.append((f"pass{i} write k={k}", c))
+    return rep
+
+
+PLANS = {
+    # name: (M, R, RS, FS, C, NT)
+    "m64": (64, [8, 8], [8, 9], 72, 8, 64),
+}
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(1)
+    for name, (M, R, RS, FS, C, NT) in PLANS.items():
+        x = rng.standard_normal(M) + 1j * rng.standard_normal(M)
+        y = run_plan(x, R, RS)
+        ref = np.fft.ifft(x) * M
+        err = abs(y - ref).max() / abs(ref).max()
+        rep = check_conflicts(M, R, RS, FS, C, NT)
+        print(f"{name}: M={M} R={R} RS={RS} FS={FS} err={err:.2e} conflicts={rep if rep else 'none'}")
+        assert err < 1e-12
