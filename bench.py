@@ -75,6 +75,10 @@ def main() -> None:
     ap.add_argument("--log2-samples", type=int, default=30, help="samples per GPU per step (2^k)")
     ap.add_argument("--frames-per-block", type=int, default=0)
     ap.add_argument("--nontemporal", type=int, default=-1)
+    ap.add_argument("--xcd-remap", type=int, default=-1)
+    ap.add_argument("--schedule", type=int, default=-1)
+    ap.add_argument("--grid", type=int, default=-1)
+    ap.add_argument("--tile-waves", type=int, default=-1)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -114,6 +118,14 @@ def main() -> None:
         ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, args.frames_per_block)
     if args.nontemporal >= 0:
         ch.set_option(L.PFB_OPT_NONTEMPORAL, args.nontemporal)
+    if args.xcd_remap >= 0:
+        ch.set_option(L.PFB_OPT_XCD_REMAP, args.xcd_remap)
+    if args.schedule >= 0:
+        ch.set_option(L.PFB_OPT_SCHEDULE, args.schedule)
+    if args.grid >= 0:
+        ch.set_option(L.PFB_OPT_GRID, args.grid)
+    if args.tile_waves >= 0:
+        ch.set_option(L.PFB_OPT_TILE_WAVES, args.tile_waves)
     hist = ch.history_samples
     halo = torch.zeros((hist, 2), dtype=tdtype, device=dev)
 

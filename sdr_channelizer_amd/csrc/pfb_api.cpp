@@ -77,6 +77,10 @@ struct pfb_handle {
   int opt_frames_per_block = 0;
   int64_t opt_host_chunk = 0;
   int opt_nontemporal = 0;
+  int opt_xcd_remap = 1;
+  int opt_schedule = 0;
+  int opt_grid = 0;
+  int opt_tile_waves = 4;
   const char* last_kernel = "";
   // host staging
   void* d_stage_in = nullptr;
@@ -127,6 +131,10 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
     p.layout = h->layout;
     p.flags = h->flags;
     p.nontemporal = h->opt_nontemporal;
+    p.xcd_remap = h->opt_xcd_remap;
+    p.schedule = h->opt_schedule;
+    p.grid_override = h->opt_grid;
+    p.tile_waves = h->opt_tile_waves;
     const bool want_fast = h->fast && h->layout == PFB_LAYOUT_FRAME_MAJOR && h->opt_kernel != 1;
     if (h->opt_kernel == 2 && !want_fast) return PFB_ERR_UNSUPPORTED;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
@@ -507,6 +515,21 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       return PFB_OK;
     case PFB_OPT_NONTEMPORAL:
       h->opt_nontemporal = value ? 1 : 0;
+      return PFB_OK;
+    case PFB_OPT_SCHEDULE:
+      if (value < 0 || value > 2) return PFB_ERR_BAD_ARG;
+      h->opt_schedule = (int)value;
+      return PFB_OK;
+    case PFB_OPT_TILE_WAVES:
+      if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return PFB_ERR_BAD_ARG;
+      h->opt_tile_waves = (int)value;
+      return PFB_OK;
+    case PFB_OPT_GRID:
+      if (value < 0 || value > (1 << 22)) return PFB_ERR_BAD_ARG;
+      h->opt_grid = (int)value;
+      return PFB_OK;
+    case PFB_OPT_XCD_REMAP:
+      h->opt_xcd_remap = value ? 1 : 0;
       return PFB_OK;
     case PFB_OPT_PROFILE:
       h->opt_profile = value ? 1 : 0;

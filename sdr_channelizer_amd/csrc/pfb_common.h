@@ -33,6 +33,11 @@ struct KernelParams {
   int layout;              // pfb_output_layout
   unsigned flags;          // PFB_FLAG_*
   int nontemporal;         // nontemporal output stores
+  int xcd_remap;           // fast kernels: consecutive runs on one XCD
+  int schedule;            // fast kernels: 0 = sliding-window runs, 1 = persistent strided chunks,
+                           //               2 = one chunk per wave, tile_waves chunks per workgroup
+  int tile_waves;          // schedule 2: waves (= adjacent chunks) per workgroup: 1, 2, 4, 8 or 16
+  int grid_override;       // schedule 1: workgroups to launch (0 = what is resident at once)
 };
 
 // sample traits -----------------------------------------------------------------

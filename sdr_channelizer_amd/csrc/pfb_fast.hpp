@@ -34,88 +34,113 @@
 namespace pfb {
 
 // ---------------------------------------------------------------------------------
-// In-register N-point DFT, kernel e^{+j 2 pi n k / N}, natural order in and out.
+// Packed-fp32 complex arithmetic.  A complex value is one v2f (re, im) in an aligned VGPR
+// pair, so every add / fma below is ONE v_pk_*_f32 issue (gfx950 issues a wave64 VALU op in
+// 4 cycles whether it is scalar-fp32 or packed: packing halves the issue count, and the
+// kernel is issue-bound long before it is flop-bound).
 
 #define PFB_DEV static __device__ __forceinline__
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr float kSqrtHalf = 0.70710678118654752f;
 constexpr float kCosPi8 = 0.92387953251128674f;
 constexpr float kSinPi8 = 0.38268343236508977f;
 
-// (r,i) *= e^{+j 2 pi K / N}, K and N compile-time, N <= 16
+PFB_DEV v2f swp(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }
+PFB_DEV v2f splat(float s) { return (v2f){s, s}; }
+PFB_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// a * (c + j s): pk_mul + pk_fma (the swap and the broadcast ride on op_sel)
+PFB_DEV v2f cmul(v2f a, float c, float s) { return fma2(swp(a), (v2f){-s, s}, a * splat(c)); }
+// same with the twiddle held as ONE register pair w = (c, s): two instructions, no extra
+// register for -s (neg_lo negates s for the real part only)
+PFB_DEV v2f cmul_w(v2f a, v2f w) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+      : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+PFB_DEV v2f add_j(v2f a, v2f b) { return fma2(swp(b), (v2f){-1.f, 1.f}, a); }  // a + j b
+PFB_DEV v2f sub_j(v2f a, v2f b) { return fma2(swp(b), (v2f){1.f, -1.f}, a); }  // a - j b
+
+// Sync between the phases of one team.  A team that is the whole workgroup uses the workgroup
+// barrier (a single-wave workgroup's barrier is free); single-wave teams inside a bigger workgroup
+// only need program order within the wave: the LDS executes one wave's accesses in order, so the
+// fences just stop the compiler from moving LDS accesses across the phase boundary.
+template <bool WAVE_LOCAL>
+PFB_DEV void team_sync() {
+  if constexpr (WAVE_LOCAL) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
+// one complex64 output element; nontemporal = streaming store (output is write-once)
+PFB_DEV void store_c64(float2* dst, v2f v, int nontemporal) {
+  if (nontemporal) __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(dst));
+  else *reinterpret_cast<v2f*>(dst) = v;
+}
+
+// ---------------------------------------------------------------------------------
+// In-register N-point DFT, kernel e^{+j 2 pi n k / N}, natural order in and out.
+
+// X[K] = E + W^K O,  X[K+N/2] = E - W^K O,   W = e^{+j 2 pi / N}, N <= 16
 template <int N, int K>
-PFB_DEV void tw_mul(float& r, float& i) {
+PFB_DEV void butterfly(v2f& lo, v2f& hi, v2f e, v2f o) {
   static_assert(16 % N == 0, "small DFT sizes only");
   constexpr int q = K * (16 / N);  // sixteenths of a turn, 0..7
   static_assert(q >= 0 && q < 8, "only the upper half plane is needed");
   if constexpr (q == 0) {
-  } else if constexpr (q == 4) {  // +j
-    const float t = r; r = -i; i = t;
-  } else if constexpr (q == 2) {  // (1+j)/sqrt2
-    const float t = (r - i) * kSqrtHalf; i = (r + i) * kSqrtHalf; r = t;
-  } else if constexpr (q == 6) {  // (-1+j)/sqrt2
-    const float t = (-r - i) * kSqrtHalf; i = (r - i) * kSqrtHalf; r = t;
+    lo = e + o; hi = e - o;
+  } else if constexpr (q == 4) {  // W = +j
+    lo = add_j(e, o); hi = sub_j(e, o);
   } else {
-    constexpr float c = (q == 1) ? kCosPi8 : (q == 3) ? kSinPi8 : (q == 5) ? -kSinPi8 : -kCosPi8;
-    constexpr float s = (q == 1) ? kSinPi8 : (q == 3) ? kCosPi8 : (q == 5) ? kCosPi8 : kSinPi8;
-    const float t = r * c - i * s; i = r * s + i * c; r = t;
+    constexpr float c = (q == 1) ? kCosPi8 : (q == 2) ? kSqrtHalf : (q == 3) ? kSinPi8
+                        : (q == 5) ? -kSinPi8 : (q == 6) ? -kSqrtHalf : -kCosPi8;
+    constexpr float s = (q == 1) ? kSinPi8 : (q == 2) ? kSqrtHalf : (q == 3) ? kCosPi8
+                        : (q == 5) ? kCosPi8 : (q == 6) ? kSqrtHalf : kSinPi8;
+    const v2f t = cmul(o, c, s);
+    lo = e + t; hi = e - t;
   }
-}
-
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-
-// one complex64 output element; nontemporal = streaming store (output is write-once)
-PFB_DEV void store_c64(float2* dst, float re, float im, int nontemporal) {
-  v2f_t v = {re, im};
-  if (nontemporal) __builtin_nontemporal_store(v, reinterpret_cast<v2f_t*>(dst));
-  else *reinterpret_cast<v2f_t*>(dst) = v;
 }
 
 template <int N> struct Dft;
 
 template <> struct Dft<2> {
-  PFB_DEV void run(float (&re)[2], float (&im)[2]) {
-    const float ar = re[0], ai = im[0];
-    re[0] = ar + re[1]; im[0] = ai + im[1];
-    re[1] = ar - re[1]; im[1] = ai - im[1];
+  PFB_DEV void run(v2f (&x)[2]) {
+    const v2f a = x[0];
+    x[0] = a + x[1]; x[1] = a - x[1];
   }
 };
 
 template <> struct Dft<4> {
-  PFB_DEV void run(float (&re)[4], float (&im)[4]) {
-    const float t0r = re[0] + re[2], t0i = im[0] + im[2];
-    const float t1r = re[0] - re[2], t1i = im[0] - im[2];
-    const float t2r = re[1] + re[3], t2i = im[1] + im[3];
-    const float t3r = re[1] - re[3], t3i = im[1] - im[3];
-    re[0] = t0r + t2r; im[0] = t0i + t2i;
-    re[2] = t0r - t2r; im[2] = t0i - t2i;
-    re[1] = t1r - t3i; im[1] = t1i + t3r;  // t1 + j t3
-    re[3] = t1r + t3i; im[3] = t1i - t3r;  // t1 - j t3
+  PFB_DEV void run(v2f (&x)[4]) {
+    const v2f t0 = x[0] + x[2], t1 = x[0] - x[2], t2 = x[1] + x[3], t3 = x[1] - x[3];
+    x[0] = t0 + t2; x[2] = t0 - t2;
+    x[1] = add_j(t1, t3); x[3] = sub_j(t1, t3);
   }
 };
 
 template <int N, int K>
-struct DftCombine {  // X[k] = E[k] + W^k O[k],  X[k+N/2] = E[k] - W^k O[k]
-  PFB_DEV void run(float (&re)[N], float (&im)[N], const float (&er)[N / 2], const float (&ei)[N / 2],
-                   float (&orr)[N / 2], float (&oi)[N / 2]) {
-    tw_mul<N, K>(orr[K], oi[K]);
-    re[K] = er[K] + orr[K]; im[K] = ei[K] + oi[K];
-    re[K + N / 2] = er[K] - orr[K]; im[K + N / 2] = ei[K] - oi[K];
-    if constexpr (K + 1 < N / 2) DftCombine<N, K + 1>::run(re, im, er, ei, orr, oi);
+struct DftCombine {
+  PFB_DEV void run(v2f (&x)[N], const v2f (&e)[N / 2], const v2f (&o)[N / 2]) {
+    butterfly<N, K>(x[K], x[K + N / 2], e[K], o[K]);
+    if constexpr (K + 1 < N / 2) DftCombine<N, K + 1>::run(x, e, o);
   }
 };
 
 template <int N> struct Dft {
-  PFB_DEV void run(float (&re)[N], float (&im)[N]) {
-    float er[N / 2], ei[N / 2], orr[N / 2], oi[N / 2];
+  PFB_DEV void run(v2f (&x)[N]) {
+    v2f e[N / 2], o[N / 2];
 #pragma unroll
-    for (int k = 0; k < N / 2; ++k) {
-      er[k] = re[2 * k]; ei[k] = im[2 * k];
-      orr[k] = re[2 * k + 1]; oi[k] = im[2 * k + 1];
-    }
-    Dft<N / 2>::run(er, ei);
-    Dft<N / 2>::run(orr, oi);
-    DftCombine<N, 0>::run(re, im, er, ei, orr, oi);
+    for (int k = 0; k < N / 2; ++k) { e[k] = x[2 * k]; o[k] = x[2 * k + 1]; }
+    Dft<N / 2>::run(e);
+    Dft<N / 2>::run(o);
+    DftCombine<N, 0>::run(x, e, o);
   }
 };
 
@@ -159,21 +184,30 @@ struct FastKernel {
 
   struct alignas(sizeof(raw_t) * CPT) RawVec { raw_t v[CPT]; };
 
-  // Row r of the stream -> CPT raw samples for this thread.  r is uniform across
-  // the workgroup, so the branches below are too.
-  PFB_DEV void load_row(const KernelParams& p, long long r, int c0, raw_t (&raw)[CPT]) {
-    if (r >= p.frames) {  // padding frames of a partial last chunk
-#pragma unroll
-      for (int cc = 0; cc < CPT; ++cc) raw[cc] = raw_t{};
-      return;
-    }
-    const long long s0 = r * D + p.base;
-    const raw_t* in = static_cast<const raw_t*>(p.in);
-    if (s0 >= 0 && p.vec_ok) {
-      const RawVec v = *reinterpret_cast<const RawVec*>(in + s0 + c0);
+  PFB_DEV v2f cvt(raw_t r) {
+    float re, im;
+    ST::cvt(r, re, im);
+    return (v2f){re, im};
+  }
+
+  // Row r of the stream -> CPT raw samples for this thread.  r is uniform across the workgroup.
+  // INTERIOR runs (every row inside `in`, aligned) take the unchecked vector load; runs that touch
+  // the history, the end of the stream or a misaligned buffer take the checked per-sample path.
+  template <bool INTERIOR>
+  PFB_DEV void load_row(const KernelParams& p, const raw_t* run_ptr, long long r, long long r_rel, int c0,
+                        raw_t (&raw)[CPT]) {
+    if constexpr (INTERIOR) {
+      const RawVec v = *reinterpret_cast<const RawVec*>(run_ptr + r_rel * D + c0);
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) raw[cc] = v.v[cc];
-    } else {  // start of the call: part of the row is history
+    } else {
+      if (r >= p.frames) {  // padding frames of a partial last chunk
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) raw[cc] = raw_t{};
+        return;
+      }
+      const long long s0 = r * D + p.base;
+      const raw_t* in = static_cast<const raw_t*>(p.in);
       const raw_t* hist = static_cast<const raw_t*>(p.hist);
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) {
@@ -185,7 +219,7 @@ struct FastKernel {
 
   template <int I>
   PFB_DEV void pass(const KernelParams& p, float2* src, float2* dst, int tid, long long f0,
-                    const float (&twr)[2][16], const float (&twi)[2][16]) {
+                    const v2f (&tw)[2][16]) {
     constexpr int R = K::R(I), S = K::S(I), KK = K::K(I), RS = K::RS(I);
     constexpr int IPF = M / R, ITEMS = C * IPF, ITERS = (ITEMS + NT - 1) / NT;
     constexpr bool LAST = (I == K::NP - 1);
@@ -196,155 +230,261 @@ struct FastKernel {
       const bool active = (ITEMS % NT == 0) || (w < ITEMS);
       const int fc = w / IPF, item = w % IPF;
       const int kk = item / S, rest = item % S;
-      float re[R], im[R];
+      v2f x[R];
       if (active) {
+        const v2f* s2 = reinterpret_cast<const v2f*>(src) + fc * K::FS + item;
 #pragma unroll
-        for (int n = 0; n < R; ++n) {
-          const float2 v = src[fc * K::FS + n * RS + item];
-          re[n] = v.x; im[n] = v.y;
-        }
+        for (int n = 0; n < R; ++n) x[n] = s2[n * RS];
       } else {
 #pragma unroll
-        for (int n = 0; n < R; ++n) { re[n] = 0.f; im[n] = 0.f; }
+        for (int n = 0; n < R; ++n) x[n] = (v2f){0.f, 0.f};
       }
-      Dft<R>::run(re, im);
+      Dft<R>::run(x);
       if constexpr (!LAST) {
         constexpr int S1 = K::S(I + 1), RS1 = K::RS(I + 1);
         // twiddle e^{+j 2 pi rest k / (R S)} = tw[rest * k * KK]
 #pragma unroll
         for (int k = 1; k < R; ++k) {
-          float c, s;
-          if constexpr (TW_REGS) { c = twr[I][k]; s = twi[I][k]; }
-          else { const float2 t = p.tw[rest * k * KK]; c = t.x; s = t.y; }
-          const float t = re[k] * c - im[k] * s;
-          im[k] = re[k] * s + im[k] * c;
-          re[k] = t;
+          v2f wk;
+          if constexpr (TW_REGS) wk = tw[I][k];
+          else { const float2 t = p.tw[rest * k * KK]; wk = (v2f){t.x, t.y}; }
+          x[k] = cmul_w(x[k], wk);
         }
         const int n1 = rest / S1, rest2 = rest % S1;
         if (active) {
+          v2f* d2 = reinterpret_cast<v2f*>(dst) + fc * K::FS + n1 * RS1 + kk * S1 + rest2;
 #pragma unroll
-          for (int k = 0; k < R; ++k) {
-            const int item2 = (kk + k * KK) * S1 + rest2;
-            dst[fc * K::FS + n1 * RS1 + item2] = make_float2(re[k], im[k]);
-          }
+          for (int k = 0; k < R; ++k) d2[k * KK * S1] = x[k];
         }
       } else {
         const long long f = f0 + fc;
         if (active && f < p.frames) {
           const bool flip_odd = (OS == 2) && (p.flags & PFB_FLAG_DEROTATE) && ((p.frame0 + f) & 1);
           const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
-          float2* row = p.out + f * M;
+          float2* row = p.out + f0 * M + fc * M;
 #pragma unroll
           for (int k = 0; k < R; ++k) {
             const int ch = kk + k * KK;
-            float vr = re[k], vi = im[k];
-            if (flip_odd && (ch & 1)) { vr = -vr; vi = -vi; }
-            store_c64(&row[ch ^ shift], vr, vi, p.nontemporal);
+            v2f v = x[k];
+            if (flip_odd && (ch & 1)) v = -v;
+            store_c64(&row[ch ^ shift], v, p.nontemporal);
           }
         }
       }
     }
   }
 
-  PFB_DEV void run(const KernelParams& p, float2* lds) {
-    const int tid = threadIdx.x;
-    const long long f_begin = (long long)blockIdx.x * p.frames_per_block;
-    if (f_begin >= p.frames) return;
-    const long long f_end = (f_begin + p.frames_per_block < p.frames) ? f_begin + p.frames_per_block : p.frames;
+  // ---- per-thread constants shared by both schedules -------------------------------------------
+  struct Consts {
+    v2f hp[(W + 1) / 2][CPT];  // taps of this thread's columns, two per register pair
+    v2f tw[2][16];             // inter-pass twiddles (c, s)
+    int upos[OS][CPT];         // LDS position of the FIR outputs inside a frame (pass-0 layout)
+    v2f conj_mul;
+  };
+
+  PFB_DEV float tap(const Consts& k, int j, int cc) { return (j & 1) ? k.hp[j >> 1][cc].y : k.hp[j >> 1][cc].x; }
+
+  PFB_DEV void setup(const KernelParams& p, int tid, Consts& k) {
     const int c0 = tid * CPT;
-
-    // taps of this thread's columns: h[p_lo + D*j], p_lo = D-1-c
-    float h[W][CPT];
+    // h[p_lo + D*j], p_lo = D-1-c
 #pragma unroll
-    for (int j = 0; j < W; ++j)
+    for (int j = 0; j < W; j += 2)
 #pragma unroll
-      for (int cc = 0; cc < CPT; ++cc) h[j][cc] = p.taps[(D - 1 - (c0 + cc)) + D * j];
-    const float im_sign = (p.flags & PFB_FLAG_CONJUGATE_INPUT) ? -1.f : 1.f;
-
-    // inter-pass twiddles for passes whose item -> thread map is fixed
-    float twr[2][16], twi[2][16];
+      for (int cc = 0; cc < CPT; ++cc) {
+        const int pl = D - 1 - (c0 + cc);
+        const float a = p.taps[pl + D * j];
+        const float b = (j + 1 < W) ? p.taps[pl + D * (j + 1)] : 0.f;
+        k.hp[j >> 1][cc] = (v2f){a, b};
+      }
+    k.conj_mul = (v2f){1.f, (p.flags & PFB_FLAG_CONJUGATE_INPUT) ? -1.f : 1.f};
 #pragma unroll
     for (int i = 0; i < K::NP - 1; ++i) {
       const int R = K::R(i), S = K::S(i), KK = K::K(i), IPF = M / R;
       if (C * IPF <= NT) {
         const int rest = (tid % IPF) % S;
 #pragma unroll
-        for (int k = 1; k < 16; ++k) {
-          if (k < R) { const float2 t = p.tw[rest * k * KK]; twr[i][k] = t.x; twi[i][k] = t.y; }
+        for (int kk = 1; kk < 16; ++kk) {
+          if (kk < R) { const float2 t = p.tw[rest * kk * KK]; k.tw[i][kk] = (v2f){t.x, t.y}; }
         }
       }
     }
-
-    // LDS position of this thread's FIR outputs inside a frame (pass-0 layout)
-    int upos[OS][CPT];
 #pragma unroll
     for (int ph = 0; ph < OS; ++ph)
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) {
         const int n = (D - 1 - (c0 + cc)) + D * ph;
-        upos[ph][cc] = (n / K::S(0)) * K::RS(0) + (n % K::S(0));
+        k.upos[ph][cc] = (n / K::S(0)) * K::RS(0) + (n % K::S(0));
       }
+  }
 
-    // window: x[i] is row (chunk_first_frame - (W-1) + i)
-    float xr[NW][CPT], xi[NW][CPT];
+  // FIR of C frames from the window x (x[i] = row f0-(W-1)+i) into LDS, then the FFT passes and the
+  // stores.  u_{p_lo + D ph}[t] = sum_q h[ph + OS q] * x[row t - ph - OS q]: one v_pk_fma_f32 per tap.
+  template <bool WAVE_LOCAL = false>
+  PFB_DEV void fir_fft_store(const KernelParams& p, const Consts& k, const v2f (&x)[NW][CPT], float2* lds, int tid,
+                             long long f0) {
+    float2* buf0 = lds;
+    float2* buf1 = K::PINGPONG ? lds + K::BUF : lds;
+#pragma unroll
+    for (int t = 0; t < C; ++t)
+#pragma unroll
+      for (int ph = 0; ph < OS; ++ph)
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) {
+          v2f acc = (v2f){0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < P; ++q) {
+            const int j = ph + OS * q;
+            acc = fma2(x[W - 1 + t - j][cc], splat(tap(k, j, cc)), acc);
+          }
+          reinterpret_cast<v2f*>(buf0)[t * K::FS + k.upos[ph][cc]] = acc * k.conj_mul;
+        }
+    team_sync<WAVE_LOCAL>();
+    pass<0>(p, buf0, buf1, tid, f0, k.tw);
+    team_sync<WAVE_LOCAL>();
+    if constexpr (K::NP == 2) {
+      pass<1>(p, buf1, nullptr, tid, f0, k.tw);
+    } else {
+      pass<1>(p, buf1, buf0, tid, f0, k.tw);
+      team_sync<WAVE_LOCAL>();
+      pass<2>(p, buf0, nullptr, tid, f0, k.tw);
+    }
+    team_sync<WAVE_LOCAL>();  // the next chunk's FIR overwrites buf0
+  }
+
+  // ---- schedule A: sliding window over a long contiguous run per workgroup ---------------------
+  template <bool INTERIOR>
+  PFB_DEV void run_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end) {
+    const int tid = threadIdx.x;
+    const int c0 = tid * CPT;
+    // uniform pointer to (row f_begin-(W-1), column 0); only dereferenced on the INTERIOR path
+    const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
+    v2f x[NW][CPT];
     raw_t raw[C][CPT];
 #pragma unroll
     for (int i = 0; i < W - 1; ++i) {
       raw_t t[CPT];
-      load_row(p, f_begin - (W - 1) + i, c0, t);
+      load_row<INTERIOR>(p, run_ptr, f_begin - (W - 1) + i, i, c0, t);
 #pragma unroll
-      for (int cc = 0; cc < CPT; ++cc) ST::cvt(t[cc], xr[i][cc], xi[i][cc]);
+      for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(t[cc]);
     }
 #pragma unroll
-    for (int t = 0; t < C; ++t) load_row(p, f_begin + t, c0, raw[t]);
-
-    float2* buf0 = lds;
-    float2* buf1 = K::PINGPONG ? lds + K::BUF : lds;
+    for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + t, W - 1 + t, c0, raw[t]);
 
     for (long long f0 = f_begin; f0 < f_end; f0 += C) {
 #pragma unroll
       for (int t = 0; t < C; ++t)
 #pragma unroll
-        for (int cc = 0; cc < CPT; ++cc) ST::cvt(raw[t][cc], xr[W - 1 + t][cc], xi[W - 1 + t][cc]);
+        for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);
       if (f0 + C < f_end) {  // prefetch the next chunk's rows under this chunk's FFT
+        const long long rel = (f0 - f_begin) + C + (W - 1);
 #pragma unroll
-        for (int t = 0; t < C; ++t) load_row(p, f0 + C + t, c0, raw[t]);
+        for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f0 + C + t, rel + t, c0, raw[t]);
       }
-
-      // FIR: u_{p_lo + D ph}[t] = sum_q h[ph + OS q] * x[row t - ph - OS q]
-#pragma unroll
-      for (int t = 0; t < C; ++t)
-#pragma unroll
-        for (int ph = 0; ph < OS; ++ph)
-#pragma unroll
-          for (int cc = 0; cc < CPT; ++cc) {
-            float ar = 0.f, ai = 0.f;
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-              const int j = ph + OS * q;
-              ar = fmaf(h[j][cc], xr[W - 1 + t - j][cc], ar);
-              ai = fmaf(h[j][cc], xi[W - 1 + t - j][cc], ai);
-            }
-            buf0[t * K::FS + upos[ph][cc]] = make_float2(ar, ai * im_sign);
-          }
-      __syncthreads();
-
-      pass<0>(p, buf0, buf1, tid, f0, twr, twi);
-      __syncthreads();
-      if constexpr (K::NP == 2) {
-        pass<1>(p, buf1, nullptr, tid, f0, twr, twi);
-      } else {
-        pass<1>(p, buf1, buf0, tid, f0, twr, twi);
-        __syncthreads();
-        pass<2>(p, buf0, nullptr, tid, f0, twr, twi);
-      }
-      __syncthreads();  // the next chunk's FIR overwrites buf0
-
+      fir_fft_store(p, k, x, lds, tid, f0);
       // slide the window by C rows
 #pragma unroll
       for (int i = 0; i < W - 1; ++i)
 #pragma unroll
-        for (int cc = 0; cc < CPT; ++cc) { xr[i][cc] = xr[i + C][cc]; xi[i][cc] = xi[i + C][cc]; }
+        for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
+    }
+  }
+
+  PFB_DEV void run(const KernelParams& p, float2* lds) {
+    // Consecutive runs go to one XCD (blocks are dealt round-robin over the 8 XCDs, so bid%8 labels
+    // the XCD).  Bijective for any grid size.
+    long long run = blockIdx.x;
+    if (p.xcd_remap) {
+      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
+      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
+    }
+    const long long f_begin = run * p.frames_per_block;
+    if (f_begin >= p.frames) return;
+    const long long f_last = f_begin + p.frames_per_block;
+    const long long f_end = f_last < p.frames ? f_last : p.frames;
+    Consts k;
+    setup(p, threadIdx.x, k);
+    // every row of the run (halo included) lies inside `in`, whole chunks only, aligned vectors
+    const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_last <= p.frames);
+    if (interior) run_impl<true>(p, k, lds, f_begin, f_end);
+    else run_impl<false>(p, k, lds, f_begin, f_end);
+  }
+
+  // ---- schedule B: persistent waves, strided chunks ---------------------------------------------
+  // The grid is sized to what is resident at once; workgroup b handles chunks b', b'+G, b'+2G, ...
+  // (b' = XCD-aware slot), so at any moment the whole chip works on ~G consecutive chunks: a compact
+  // window sweeping through the stream (DRAM pages and TLB entries are reused while hot; measured
+  // with tools/membench2: the same byte mix moves 15 % faster than with long per-wave runs).  Each
+  // chunk re-reads its W-1 halo rows; its neighbours (same XCD, same step) read those rows as their
+  // own at the same time, so they come from L2, not HBM.  All NW rows of the next chunk are
+  // prefetched into registers under the current chunk's arithmetic.
+  PFB_DEV void load_chunk(const KernelParams& p, long long chunk, int c0, raw_t (&raw)[NW][CPT]) {
+    const long long f0 = chunk * C;
+    const long long s_first = (f0 - (W - 1)) * D + p.base;
+    const bool interior = p.vec_ok && s_first >= 0 && (f0 + C <= p.frames);
+    const raw_t* ptr = static_cast<const raw_t*>(p.in) + s_first;  // uniform; only used when interior
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < NW; ++i) load_row<true>(p, ptr, 0, i, c0, raw[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NW; ++i) load_row<false>(p, ptr, f0 - (W - 1) + i, i, c0, raw[i]);
+    }
+  }
+
+  // ---- schedule C: one chunk per wave, NWV adjacent chunks per (non-persistent) workgroup ---------
+  // The dispatcher hands out workgroups in order, so the chip sweeps the stream as one compact,
+  // monotonically advancing window (the fastest shape in tools/membench2); the W-1 halo rows a wave
+  // shares with its neighbours in the workgroup are served by that CU's L1, and the ones shared with
+  // the previous workgroup by the XCD's L2 (consecutive tiles are remapped onto one XCD).
+  template <int NWV>
+  PFB_DEV void run_tile(const KernelParams& p, float2* lds_all) {
+    static_assert(NT == 64, "one wave per chunk");
+    const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    const int c0 = tid * CPT;
+    const long long nchunks = (p.frames + C - 1) / C;
+    long long tile = blockIdx.x;
+    if (p.xcd_remap) {
+      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = tile & 7;
+      tile = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (tile >> 3);
+    }
+    const long long chunk = tile * NWV + wave;
+    if (chunk >= nchunks) return;
+    float2* lds = lds_all + wave * K::LDS_ELEMS;
+    Consts k;
+    setup(p, tid, k);
+    raw_t raw[NW][CPT];
+    load_chunk(p, chunk, c0, raw);
+    v2f x[NW][CPT];
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(raw[i][cc]);
+    fir_fft_store<true>(p, k, x, lds, tid, chunk * C);
+  }
+
+  PFB_DEV void run_strided(const KernelParams& p, float2* lds) {
+    const int tid = threadIdx.x;
+    const int c0 = tid * CPT;
+    const long long nchunks = (p.frames + C - 1) / C;
+    const long long nb = gridDim.x;
+    long long chunk = blockIdx.x;
+    if (p.xcd_remap) {  // slot = xcd * (nb/8) + index inside the XCD (bijective for any nb)
+      const long long q = nb >> 3, r = nb & 7, xc = chunk & 7;
+      chunk = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (chunk >> 3);
+    }
+    if (chunk >= nchunks) return;
+    Consts k;
+    setup(p, tid, k);
+    raw_t raw[NW][CPT];
+    load_chunk(p, chunk, c0, raw);
+    for (; chunk < nchunks; chunk += nb) {
+      v2f x[NW][CPT];
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(raw[i][cc]);
+      if (chunk + nb < nchunks) load_chunk(p, chunk + nb, c0, raw);
+      fir_fft_store(p, k, x, lds, tid, chunk * C);
     }
   }
 };
@@ -356,9 +496,60 @@ __global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_fast_kernel(const Ker
 }
 
 template <class K>
+__global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_strided_kernel(const KernelParams p) {
+  __shared__ float2 lds[K::LDS_ELEMS];
+  FastKernel<K>::run_strided(p, lds);
+}
+
+template <class K, int NWV>
+__global__ void __launch_bounds__(64 * NWV) pfb_tile_kernel(const KernelParams p) {
+  __shared__ float2 lds[NWV * K::LDS_ELEMS];
+  FastKernel<K>::template run_tile<NWV>(p, lds);
+}
+
+template <class K, int NWV>
+hipError_t launch_tile(const KernelParams& p, hipStream_t s) {
+  const long long nchunks = (p.frames + K::C - 1) / K::C;
+  const long long tiles = (nchunks + NWV - 1) / NWV;
+  hipLaunchKernelGGL((pfb_tile_kernel<K, NWV>), dim3((unsigned)tiles), dim3(64 * NWV), 0, s, p);
+  return hipGetLastError();
+}
+
+template <class K>
 hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
+  if (p.frames <= 0) return hipSuccess;
+  if constexpr (K::NT == 64) {
+    if (p.schedule == 2) {  // one chunk per wave, tile_waves adjacent chunks per workgroup
+      switch (p.tile_waves) {
+        case 1: return launch_tile<K, 1>(p, s);
+        case 2: return launch_tile<K, 2>(p, s);
+        case 4: return launch_tile<K, 4>(p, s);
+        case 8: return launch_tile<K, 8>(p, s);
+        case 16: return launch_tile<K, 16>(p, s);
+        default: return hipErrorInvalidValue;
+      }
+    }
+  }
+  if (p.schedule == 1) {  // persistent strided chunks
+    static int resident = 0;  // workgroups resident at once on this device class
+    if (resident == 0) {
+      int per_cu = 0, dev = 0;
+      hipDeviceProp_t prop;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pfb_strided_kernel<K>, K::NT, 0);
+      if (e == hipSuccess) e = hipGetDevice(&dev);
+      if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+      if (e != hipSuccess) return e;
+      resident = per_cu * prop.multiProcessorCount;
+      if (resident < 8) resident = 8;
+    }
+    const long long nchunks = (p.frames + K::C - 1) / K::C;
+    long long grid = p.grid_override > 0 ? p.grid_override : resident;
+    if (grid > nchunks) grid = nchunks;
+    if (grid >= 8) grid -= grid % 8;
+    hipLaunchKernelGGL(pfb_strided_kernel<K>, dim3((unsigned)grid), dim3(K::NT), 0, s, p);
+    return hipGetLastError();
+  }
   const long long blocks = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
-  if (blocks <= 0) return hipSuccess;
   hipLaunchKernelGGL(pfb_fast_kernel<K>, dim3((unsigned)blocks), dim3(K::NT), 0, s, p);
   return hipGetLastError();
 }

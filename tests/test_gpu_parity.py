@@ -256,3 +256,31 @@ def test_large_stream_interior_windows(oracle):
         got = y[f0:f0 + 64].cpu().numpy()
         assert np.abs(got - want).max() / max(np.abs(want).max(), 0.05) < REL_TOL, f0
     assert bool(torch.isfinite(torch.view_as_real(y)).all())
+
+
+@pytest.mark.parametrize("opts", [{L.PFB_OPT_SCHEDULE: 0}, {L.PFB_OPT_SCHEDULE: 0, L.PFB_OPT_FRAMES_PER_BLOCK: 40},
+                                  {L.PFB_OPT_SCHEDULE: 1}, {L.PFB_OPT_SCHEDULE: 1, L.PFB_OPT_GRID: 24},
+                                  {L.PFB_OPT_SCHEDULE: 1, L.PFB_OPT_XCD_REMAP: 0},
+                                  {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 1},
+                                  {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 4},
+                                  {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 16, L.PFB_OPT_XCD_REMAP: 0},
+                                  {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_NONTEMPORAL: 1}])
+def test_every_schedule_gives_identical_bits(oracle, opts):
+    """The schedules only change which wave computes which frames, never the arithmetic."""
+    M, P = 64, 12
+    n = M * 5003 + 11                      # partial last chunk, carried tail
+    iq = synth.pulsed_iq_numpy(n, 12, np.int16, seed=13)
+    h = oracle.design_prototype(M, P).astype(np.float32)
+    with Channelizer(M, taps=h, bit_width=12) as ch:
+        ch.set_option(L.PFB_OPT_KERNEL, 2)
+        ch.set_option(L.PFB_OPT_SCHEDULE, 0)
+        ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, 512)
+        ref = ch(iq)
+        ch.reset()
+        for k, v in opts.items():
+            ch.set_option(k, v)
+        got = ch(iq[:M * 1000 + 5])          # second call starts mid-frame: unaligned, history rows
+        got2 = ch(iq[M * 1000 + 5:])
+    want = oracle_run(oracle, iq, h, M, P, M, 12)
+    assert rel(ref, want) < REL_TOL
+    assert np.array_equal(np.concatenate([got, got2]), ref)
