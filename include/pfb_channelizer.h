@@ -172,7 +172,8 @@ typedef enum pfb_option {
   PFB_OPT_XCD_REMAP = 5,        /* 1 (default) = consecutive runs of frames stay on one XCD      */
   PFB_OPT_SCHEDULE = 6,         /* fast kernels: 0 = one sliding-window run per workgroup,       */
                                 /* 1 = persistent waves over strided chunks, 2 = one chunk per   */
-                                /* wave with adjacent chunks grouped into workgroups             */
+                                /* wave with adjacent chunks grouped into workgroups, 3 = short  */
+                                /* sliding runs whose halo rows are shared through LDS           */
   PFB_OPT_GRID = 7,             /* schedule 1: workgroups to launch (0 = all that are resident)  */
   PFB_OPT_TILE_WAVES = 8        /* schedule 2: waves (adjacent chunks) per workgroup: 1,2,4,8,16 */
 } pfb_option;

@@ -66,6 +66,8 @@ struct pfb_handle {
   int hist_samples = 0;    // M*P + D
   float* d_taps = nullptr;   // M*P, scaled by 2^-(bit_width-1)
   float2* d_tw = nullptr;    // M
+  float* d_taps_lane = nullptr;   // fast kernels: per-column tap table
+  float2* d_tw_lane = nullptr;    // fast kernels: inter-pass twiddle rows
   void* d_hist[2] = {nullptr, nullptr};
   int cur = 0;               // which history buffer is current
   uint32_t phase = 0;        // samples carried since the last frame boundary (0..D-1)
@@ -78,9 +80,9 @@ struct pfb_handle {
   int64_t opt_host_chunk = 0;
   int opt_nontemporal = 0;
   int opt_xcd_remap = 1;
-  int opt_schedule = 0;
+  int opt_schedule = 3;
   int opt_grid = 0;
-  int opt_tile_waves = 4;
+  int opt_tile_waves = 8;
   const char* last_kernel = "";
   // host staging
   void* d_stage_in = nullptr;
@@ -99,6 +101,8 @@ void free_handle(pfb_handle* h) {
   DeviceGuard g(h->device);
   (void)hipFree(h->d_taps);
   (void)hipFree(h->d_tw);
+  (void)hipFree(h->d_taps_lane);
+  (void)hipFree(h->d_tw_lane);
   (void)hipFree(h->d_hist[0]);
   (void)hipFree(h->d_hist[1]);
   (void)hipFree(h->d_stage_in);
@@ -119,6 +123,8 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
     p.out = static_cast<float2*>(d_out);
     p.taps = h->d_taps;
     p.tw = h->d_tw;
+    p.taps_lane = h->d_taps_lane;
+    p.tw_lane = h->d_tw_lane;
     p.n_in = (long long)n;
     p.frames = (long long)frames;
     p.frame0 = (long long)h->frame_index;
@@ -152,6 +158,7 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
       const int c = h->fast->chunk_frames;
       int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
       fpb = ((fpb + c - 1) / c) * c;
+      if (h->opt_schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
       p.frames_per_block = fpb;
       const int cpt = h->fast->cols_per_thread;
       const int bmod = ((p.base % cpt) + cpt) % cpt;
@@ -351,6 +358,12 @@ int pfb_create(const pfb_config* cfg, pfb_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->d_hist[1], hist_bytes);
   if (e == hipSuccess) e = hipMemcpy(h->d_taps, taps.data(), L * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_tw, tw.data(), M * sizeof(float2), hipMemcpyHostToDevice);
+  if (e == hipSuccess && h->fast) {
+    e = hipMalloc((void**)&h->d_taps_lane, (size_t)h->fast->taps_lane_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_tw_lane, (size_t)h->fast->tw_lane_elems * sizeof(float2));
+    if (e == hipSuccess) e = h->fast->init_tables(h->d_taps, h->d_tw, h->d_taps_lane, h->d_tw_lane, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  }
   if (e == hipSuccess) e = hipMemset(h->d_hist[0], 0, hist_bytes);
   if (e == hipSuccess) e = hipMemset(h->d_hist[1], 0, hist_bytes);
   if (e != hipSuccess) {
@@ -517,11 +530,11 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_nontemporal = value ? 1 : 0;
       return PFB_OK;
     case PFB_OPT_SCHEDULE:
-      if (value < 0 || value > 2) return PFB_ERR_BAD_ARG;
+      if (value < 0 || value > 3) return PFB_ERR_BAD_ARG;
       h->opt_schedule = (int)value;
       return PFB_OK;
     case PFB_OPT_TILE_WAVES:
-      if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return PFB_ERR_BAD_ARG;
+      if (value < 1 || value > 16) return PFB_ERR_BAD_ARG;
       h->opt_tile_waves = (int)value;
       return PFB_OK;
     case PFB_OPT_GRID:

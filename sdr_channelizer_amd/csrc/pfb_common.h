@@ -19,6 +19,8 @@ struct KernelParams {
   float2* out;             // frames*M complex64
   const float* taps;       // M*P taps, pre-scaled by 2^-(bit_width-1) (exact)
   const float2* tw;        // tw[m] = exp(+j 2 pi m / M), m = 0..M-1 (from float64)
+  const float* taps_lane;  // fast kernels: taps_lane[c][j] = taps[(D-1-c) + D*j], rows padded to float4s
+  const float2* tw_lane;   // fast kernels: inter-pass twiddle rows, see pfb_fast.hpp
   long long n_in;          // samples in `in`
   long long frames;        // frames to produce
   long long frame0;        // global index of local frame 0 (PFB_FLAG_DEROTATE)
@@ -74,8 +76,12 @@ static inline int bytes_per_sample(int fmt) {
 // Launchers implemented in pfb_kernels.hip ------------------------------------------
 // Returns nullptr if there is no fast kernel for this configuration.
 using FastLaunchFn = hipError_t (*)(const KernelParams&, hipStream_t);
+using FastInitFn = hipError_t (*)(const float* taps, const float2* tw, float* taps_lane, float2* tw_lane, hipStream_t);
 struct FastKernelInfo {
   FastLaunchFn launch;
+  FastInitFn init_tables;
+  int taps_lane_floats;
+  int tw_lane_elems;
   const char* name;
   int chunk_frames;        // C: frames_per_block must be a multiple of this
   int default_frames_per_block;

@@ -61,6 +61,14 @@ PFB_DEV v2f cmul_w(v2f a, v2f w) {
       : "=v"(r) : "v"(a), "v"(w), "v"(t));
   return r;
 }
+// acc += x * h.lo / h.hi (tap broadcast to both halves by op_sel): two taps share one register pair,
+// which the compiler will not do by itself (it materialises a splat pair per tap)
+PFB_DEV void fma_tap_lo(v2f& acc, v2f x, v2f h) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(h));
+}
+PFB_DEV void fma_tap_hi(v2f& acc, v2f x, v2f h) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(h));
+}
 PFB_DEV v2f add_j(v2f a, v2f b) { return fma2(swp(b), (v2f){-1.f, 1.f}, a); }  // a + j b
 PFB_DEV v2f sub_j(v2f a, v2f b) { return fma2(swp(b), (v2f){1.f, -1.f}, a); }  // a - j b
 
@@ -161,6 +169,10 @@ struct FastCfg {
   static constexpr int RS(int i) { return i == 0 ? RS0_ : i == 1 ? RS1_ : RS2_; }
   static constexpr int S(int i) { int s = 1; for (int j = i + 1; j < NP; ++j) s *= R(j); return s; }
   static constexpr int K(int i) { int k = 1; for (int j = 0; j < i; ++j) k *= R(j); return k; }
+  static constexpr int WP = (W + 3) / 4 * 4;  // taps per column padded to whole float4s
+  static constexpr int TAPS_LANE_FLOATS = D * WP;  // per-column tap table built by init_tables
+  static constexpr int TW_OFF(int i) { int o = 0; for (int j = 0; j < i; ++j) o += S(j) * R(j); return o; }
+  static constexpr int TW_LANE_ELEMS = TW_OFF(NP - 1) > 0 ? TW_OFF(NP - 1) : 1;  // inter-pass twiddle rows
   static constexpr int BUF = C * FS;   // one chunk buffer (complex elements)
   static constexpr int LDS_ELEMS = BUF * (PINGPONG ? 2 : 1);
   static_assert(D % CPT == 0 && NT % 64 == 0, "whole waves");
@@ -284,27 +296,37 @@ struct FastKernel {
 
   PFB_DEV float tap(const Consts& k, int j, int cc) { return (j & 1) ? k.hp[j >> 1][cc].y : k.hp[j >> 1][cc].x; }
 
+  // Per-thread constants come from two small L2-resident tables laid out for 16-byte loads (built once
+  // per handle by init_tables): taps_lane[c][0..WP) = h[(D-1-c) + D*j] and, per non-final pass,
+  // tw_lane[rest][k] = e^{+j 2 pi rest k / (R S)}.  A wave needs WP/4 + R/2 wide loads instead of
+  // W + R-1 narrow ones, which is what makes short-lived workgroups affordable.
   PFB_DEV void setup(const KernelParams& p, int tid, Consts& k) {
     const int c0 = tid * CPT;
-    // h[p_lo + D*j], p_lo = D-1-c
 #pragma unroll
-    for (int j = 0; j < W; j += 2)
+    for (int cc = 0; cc < CPT; ++cc) {
+      const float4* tl = reinterpret_cast<const float4*>(p.taps_lane + (size_t)(c0 + cc) * K::WP);
 #pragma unroll
-      for (int cc = 0; cc < CPT; ++cc) {
-        const int pl = D - 1 - (c0 + cc);
-        const float a = p.taps[pl + D * j];
-        const float b = (j + 1 < W) ? p.taps[pl + D * (j + 1)] : 0.f;
-        k.hp[j >> 1][cc] = (v2f){a, b};
+      for (int q4 = 0; q4 < K::WP / 4; ++q4) {
+        const float4 v = tl[q4];
+        if (2 * q4 < (W + 1) / 2) k.hp[2 * q4][cc] = (v2f){v.x, v.y};
+        if (2 * q4 + 1 < (W + 1) / 2) k.hp[2 * q4 + 1][cc] = (v2f){v.z, v.w};
       }
+    }
     k.conj_mul = (v2f){1.f, (p.flags & PFB_FLAG_CONJUGATE_INPUT) ? -1.f : 1.f};
 #pragma unroll
     for (int i = 0; i < K::NP - 1; ++i) {
-      const int R = K::R(i), S = K::S(i), KK = K::K(i), IPF = M / R;
+      constexpr int dummy = 0; (void)dummy;
+      const int R = K::R(i), S = K::S(i), IPF = M / R;
       if (C * IPF <= NT) {
         const int rest = (tid % IPF) % S;
+        const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(i) + rest * R);
 #pragma unroll
-        for (int kk = 1; kk < 16; ++kk) {
-          if (kk < R) { const float2 t = p.tw[rest * kk * KK]; k.tw[i][kk] = (v2f){t.x, t.y}; }
+        for (int k2 = 0; k2 < 8; ++k2) {
+          if (2 * k2 < R) {
+            const float4 v = t4[k2];
+            k.tw[i][2 * k2] = (v2f){v.x, v.y};
+            k.tw[i][2 * k2 + 1] = (v2f){v.z, v.w};
+          }
         }
       }
     }
@@ -325,19 +347,25 @@ struct FastKernel {
     float2* buf0 = lds;
     float2* buf1 = K::PINGPONG ? lds + K::BUF : lds;
 #pragma unroll
-    for (int t = 0; t < C; ++t)
+    for (int ph = 0; ph < OS; ++ph)
 #pragma unroll
-      for (int ph = 0; ph < OS; ++ph)
+      for (int cc = 0; cc < CPT; ++cc) {
+        v2f acc[C];  // C independent chains: tap-major order keeps dependent pk_fma's C issues apart
 #pragma unroll
-        for (int cc = 0; cc < CPT; ++cc) {
-          v2f acc = (v2f){0.f, 0.f};
+        for (int t = 0; t < C; ++t) acc[t] = (v2f){0.f, 0.f};
 #pragma unroll
-          for (int q = 0; q < P; ++q) {
-            const int j = ph + OS * q;
-            acc = fma2(x[W - 1 + t - j][cc], splat(tap(k, j, cc)), acc);
+        for (int q = 0; q < P; ++q) {
+          const int j = ph + OS * q;
+#pragma unroll
+          for (int t = 0; t < C; ++t) {
+            if (j & 1) fma_tap_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+            else fma_tap_lo(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
           }
-          reinterpret_cast<v2f*>(buf0)[t * K::FS + k.upos[ph][cc]] = acc * k.conj_mul;
         }
+#pragma unroll
+        for (int t = 0; t < C; ++t)
+          reinterpret_cast<v2f*>(buf0)[t * K::FS + k.upos[ph][cc]] = acc[t] * k.conj_mul;
+      }
     team_sync<WAVE_LOCAL>();
     pass<0>(p, buf0, buf1, tid, f0, k.tw);
     team_sync<WAVE_LOCAL>();
@@ -407,6 +435,88 @@ struct FastKernel {
     const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_last <= p.frames);
     if (interior) run_impl<true>(p, k, lds, f_begin, f_end);
     else run_impl<false>(p, k, lds, f_begin, f_end);
+  }
+
+  // ---- schedule D: sliding windows with the halo shared inside the workgroup -------------------------
+  // A workgroup of NWV waves covers NWV*L consecutive frames, wave w the L frames [w*L, (w+1)*L) with its
+  // own register window.  Short runs keep the whole chip inside one dense, in-order sweeping window
+  // (DRAM rows are finished while open: tools/membench2), but a short run's W-1 halo rows would be
+  // fetched from HBM twice -- by this wave now and by its predecessor, as the tail of ITS run, a few
+  // microseconds later.  So each wave PUBLISHES the raw halo rows it loads in an LDS slot, and its
+  // predecessor takes the last W-1 rows of its run from that slot instead of from memory: every row
+  // is fetched once, except the W-1 rows at workgroup boundaries ((W-1)/(NWV*L) extra reads).
+  template <bool INTERIOR, int NWV, int L>
+  PFB_DEV void shared_impl(const KernelParams& p, const Consts& k, float2* lds, raw_t* halo_mine,
+                           const raw_t* halo_next, int wave, long long f_begin) {
+    static_assert(L % C == 0 && L >= W - 1, "runs are whole chunks and at least one halo long");
+    constexpr int TAIL0 = L - (W - 1);  // first row of the run that the successor publishes
+    const int tid = threadIdx.x & 63;
+    const int c0 = tid * CPT;
+    const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
+    v2f x[NW][CPT];
+    raw_t raw[C][CPT];
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) {
+      raw_t t[CPT];
+      load_row<INTERIOR>(p, run_ptr, f_begin - (W - 1) + i, i, c0, t);
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) {
+        x[i][cc] = cvt(t[cc]);
+        if constexpr (INTERIOR) halo_mine[i * D + c0 + cc] = t[cc];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + t, W - 1 + t, c0, raw[t]);
+    __syncthreads();  // every wave's halo slot is published
+    const bool tail_from_lds = INTERIOR && (wave < NWV - 1);
+#pragma unroll
+    for (int ci = 0; ci < L / C; ++ci) {
+#pragma unroll
+      for (int t = 0; t < C; ++t) {
+        const int r = ci * C + t;
+        if (r >= TAIL0 && tail_from_lds) {
+#pragma unroll
+          for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(halo_next[(r - TAIL0) * D + c0 + cc]);
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);
+        }
+      }
+      if (ci + 1 < L / C) {  // prefetch the next chunk's rows (those not coming from LDS)
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+          const int r = (ci + 1) * C + t;
+          if (!(r >= TAIL0 && tail_from_lds)) load_row<INTERIOR>(p, run_ptr, f_begin + r, W - 1 + r, c0, raw[t]);
+        }
+      }
+      fir_fft_store<true>(p, k, x, lds, tid, f_begin + ci * C);
+#pragma unroll
+      for (int i = 0; i < W - 1; ++i)
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
+    }
+  }
+
+  template <int NWV, int L>
+  PFB_DEV void run_shared(const KernelParams& p, float2* lds_fft, raw_t* lds_halo) {
+    static_assert(NT == 64, "one wave per run");
+    const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    long long blk = blockIdx.x;
+    if (p.xcd_remap) {
+      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = blk & 7;
+      blk = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (blk >> 3);
+    }
+    const long long f_blk = blk * (long long)(NWV * L);
+    const long long f_begin = f_blk + (long long)wave * L;
+    Consts k;
+    setup(p, tid, k);
+    float2* lds = lds_fft + wave * K::LDS_ELEMS;
+    raw_t* halo_mine = lds_halo + wave * ((W - 1) * D);
+    const raw_t* halo_next = lds_halo + (wave + 1) * ((W - 1) * D);
+    // workgroup-uniform: every row of every run lies inside `in`, whole runs only, aligned vectors
+    const bool interior = p.vec_ok && ((f_blk - (W - 1)) * D + p.base >= 0) && (f_blk + NWV * L <= p.frames);
+    if (interior) shared_impl<true, NWV, L>(p, k, lds, halo_mine, halo_next, wave, f_begin);
+    else shared_impl<false, NWV, L>(p, k, lds, halo_mine, halo_next, wave, f_begin);
   }
 
   // ---- schedule B: persistent waves, strided chunks ---------------------------------------------
@@ -489,6 +599,30 @@ struct FastKernel {
   }
 };
 
+// Builds the per-column tap table and the inter-pass twiddle rows (once per handle).
+template <class K>
+__global__ void __launch_bounds__(256) pfb_init_tables_kernel(const float* taps, const float2* tw, float* taps_lane,
+                                                             float2* tw_lane) {
+  for (int idx = threadIdx.x; idx < K::TAPS_LANE_FLOATS; idx += 256) {
+    const int c = idx / K::WP, j = idx % K::WP;
+    taps_lane[idx] = (j < K::W) ? taps[(K::D - 1 - c) + K::D * j] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < K::NP - 1; ++i) {
+    const int R = K::R(i), S = K::S(i), KK = K::K(i);
+    for (int idx = threadIdx.x; idx < S * R; idx += 256) {
+      const int rest = idx / R, kk = idx % R;
+      tw_lane[K::TW_OFF(i) + idx] = tw[rest * kk * KK];
+    }
+  }
+}
+
+template <class K>
+hipError_t init_tables(const float* taps, const float2* tw, float* taps_lane, float2* tw_lane, hipStream_t s) {
+  hipLaunchKernelGGL(pfb_init_tables_kernel<K>, dim3(1), dim3(256), 0, s, taps, tw, taps_lane, tw_lane);
+  return hipGetLastError();
+}
+
 template <class K>
 __global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_fast_kernel(const KernelParams p) {
   __shared__ float2 lds[K::LDS_ELEMS];
@@ -496,7 +630,7 @@ __global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_fast_kernel(const Ker
 }
 
 template <class K>
-__global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_strided_kernel(const KernelParams p) {
+__global__ void __launch_bounds__(K::NT, (K::MIN_WAVES > 3 ? 3 : K::MIN_WAVES)) pfb_strided_kernel(const KernelParams p) {
   __shared__ float2 lds[K::LDS_ELEMS];
   FastKernel<K>::run_strided(p, lds);
 }
@@ -515,9 +649,65 @@ hipError_t launch_tile(const KernelParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <class K, int NWV, int L>
+__global__ void __launch_bounds__(64 * NWV) pfb_shared_kernel(const KernelParams p) {
+  using raw_t = typename SampleT<K::FMT>::raw_t;
+  __shared__ float2 lds_fft[NWV * K::LDS_ELEMS];
+  __shared__ raw_t lds_halo[(NWV + 1) * (K::W - 1) * K::D];
+  FastKernel<K>::template run_shared<NWV, L>(p, lds_fft, lds_halo);
+}
+
+template <class K, int NWV, int L>
+hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s);
+
+template <class K, int NWV, int L>
+hipError_t launch_shared(const KernelParams& p, hipStream_t s) {
+  constexpr size_t kLds = sizeof(float2) * NWV * K::LDS_ELEMS +
+                          sizeof(typename SampleT<K::FMT>::raw_t) * (NWV + 1) * (K::W - 1) * K::D;
+  if constexpr (kLds > 160 * 1024) {
+    return hipErrorInvalidValue;  // does not fit one CU's LDS for this sample format
+  } else {
+    return launch_shared_impl<K, NWV, L>(p, s);
+  }
+}
+
+template <class K, int NWV, int L>
+hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s) {
+  const long long per = (long long)NWV * L;
+  const long long blocks = (p.frames + per - 1) / per;
+  hipLaunchKernelGGL((pfb_shared_kernel<K, NWV, L>), dim3((unsigned)blocks), dim3(64 * NWV), 0, s, p);
+  return hipGetLastError();
+}
+
 template <class K>
 hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   if (p.frames <= 0) return hipSuccess;
+  if constexpr (K::NT == 64 && K::D == K::M) {
+    if (p.schedule == 3) {  // shared-halo sliding windows: tile_waves runs of frames_per_block frames
+      const int key = p.tile_waves * 1000 + p.frames_per_block;
+      if (key == 8024) return launch_shared<K, 8, 24>(p, s);
+      if (key == 8032) return launch_shared<K, 8, 32>(p, s);
+      if constexpr (K::FMT == PFB_FMT_INT16_IQ) {  // tuning sweep set (int16 only, keeps build time sane)
+        switch (key) {
+          case 4032: return launch_shared<K, 4, 32>(p, s);
+          case 4024: return launch_shared<K, 4, 24>(p, s);
+          case 6024: return launch_shared<K, 6, 24>(p, s);
+          case 8016: return launch_shared<K, 8, 16>(p, s);
+          case 8040: return launch_shared<K, 8, 40>(p, s);
+          case 8048: return launch_shared<K, 8, 48>(p, s);
+          case 8064: return launch_shared<K, 8, 64>(p, s);
+          case 10024: return launch_shared<K, 10, 24>(p, s);
+          case 12016: return launch_shared<K, 12, 16>(p, s);
+          case 12024: return launch_shared<K, 12, 24>(p, s);
+          case 16016: return launch_shared<K, 16, 16>(p, s);
+          case 16024: return launch_shared<K, 16, 24>(p, s);
+          case 16032: return launch_shared<K, 16, 32>(p, s);
+          default: break;
+        }
+      }
+      return launch_shared<K, 8, 24>(p, s);  // any other shape: the tuned default
+    }
+  }
   if constexpr (K::NT == 64) {
     if (p.schedule == 2) {  // one chunk per wave, tile_waves adjacent chunks per workgroup
       switch (p.tile_waves) {

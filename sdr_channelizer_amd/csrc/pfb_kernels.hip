@@ -195,7 +195,9 @@ struct FastEntry { int M, P, D, fmt; FastKernelInfo info; };
 
 template <class K>
 constexpr FastEntry entry(const char* name, int default_fpb) {
-  return FastEntry{K::M, K::P, K::D, K::FMT, FastKernelInfo{&launch_fast<K>, name, K::C, default_fpb, K::CPT}};
+  return FastEntry{K::M, K::P, K::D, K::FMT,
+                   FastKernelInfo{&launch_fast<K>, &init_tables<K>, K::TAPS_LANE_FLOATS, K::TW_LANE_ELEMS, name, K::C,
+                                  default_fpb, K::CPT}};
 }
 
 static const FastEntry kFastTable[] = {

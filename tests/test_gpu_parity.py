@@ -179,6 +179,7 @@ def test_fast_and_generic_kernels_agree():
     iq = synth.pulsed_iq_numpy(M * 4096 + 1000, 12, np.int16, seed=77)
     h = np.random.default_rng(6).standard_normal(M * P).astype(np.float32) / M
     with Channelizer(M, taps=h, bit_width=12) as ch:
+        ch.set_option(L.PFB_OPT_SCHEDULE, 0)
         ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, 104)  # not a multiple of the grid: partial last block
         fast = ch(iq)
         assert ch.last_kernel.startswith("pfb_fast")
@@ -264,7 +265,12 @@ def test_large_stream_interior_windows(oracle):
                                   {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 1},
                                   {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 4},
                                   {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 16, L.PFB_OPT_XCD_REMAP: 0},
-                                  {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_NONTEMPORAL: 1}])
+                                  {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_NONTEMPORAL: 1},
+                                  {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_FRAMES_PER_BLOCK: 32},
+                                  {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 4, L.PFB_OPT_FRAMES_PER_BLOCK: 64},
+                                  {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 16, L.PFB_OPT_FRAMES_PER_BLOCK: 16,
+                                   L.PFB_OPT_XCD_REMAP: 0},
+                                  {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_FRAMES_PER_BLOCK: 24}])
 def test_every_schedule_gives_identical_bits(oracle, opts):
     """The schedules only change which wave computes which frames, never the arithmetic."""
     M, P = 64, 12
