@@ -170,7 +170,8 @@ typedef enum pfb_option {
   PFB_OPT_NONTEMPORAL = 3,      /* 1 = nontemporal output stores                               */
   PFB_OPT_PROFILE = 4,          /* 1 = bracket every channelizer kernel launch with HIP events  */
   PFB_OPT_XCD_REMAP = 5,        /* 1 (default) = consecutive runs of frames stay on one XCD      */
-  PFB_OPT_SCHEDULE = 6,         /* fast kernels: 0 = one sliding-window run per workgroup,       */
+  PFB_OPT_SCHEDULE = 6,         /* fast kernels: -1 (default) = best measured for the kernel,    */
+                                /* 0 = one sliding-window run per workgroup,                     */
                                 /* 1 = persistent waves over strided chunks, 2 = one chunk per   */
                                 /* wave with adjacent chunks grouped into workgroups, 3 = short  */
                                 /* sliding runs whose halo rows are shared through LDS           */

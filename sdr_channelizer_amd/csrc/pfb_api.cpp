@@ -80,7 +80,7 @@ struct pfb_handle {
   int64_t opt_host_chunk = 0;
   int opt_nontemporal = 0;
   int opt_xcd_remap = 1;
-  int opt_schedule = 3;
+  int opt_schedule = -1;  // -1: the instantiation's measured default
   int opt_grid = 0;
   int opt_tile_waves = 8;
   const char* last_kernel = "";
@@ -138,7 +138,6 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
     p.flags = h->flags;
     p.nontemporal = h->opt_nontemporal;
     p.xcd_remap = h->opt_xcd_remap;
-    p.schedule = h->opt_schedule;
     p.grid_override = h->opt_grid;
     p.tile_waves = h->opt_tile_waves;
     const bool want_fast = h->fast && h->layout == PFB_LAYOUT_FRAME_MAJOR && h->opt_kernel != 1;
@@ -158,7 +157,8 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
       const int c = h->fast->chunk_frames;
       int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
       fpb = ((fpb + c - 1) / c) * c;
-      if (h->opt_schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
+      p.schedule = h->opt_schedule >= 0 ? h->opt_schedule : h->fast->default_schedule;
+      if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
       p.frames_per_block = fpb;
       const int cpt = h->fast->cols_per_thread;
       const int bmod = ((p.base % cpt) + cpt) % cpt;
@@ -530,7 +530,7 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_nontemporal = value ? 1 : 0;
       return PFB_OK;
     case PFB_OPT_SCHEDULE:
-      if (value < 0 || value > 3) return PFB_ERR_BAD_ARG;
+      if (value < -1 || value > 3) return PFB_ERR_BAD_ARG;
       h->opt_schedule = (int)value;
       return PFB_OK;
     case PFB_OPT_TILE_WAVES:

@@ -86,6 +86,7 @@ struct FastKernelInfo {
   int chunk_frames;        // C: frames_per_block must be a multiple of this
   int default_frames_per_block;
   int cols_per_thread;     // CPT: vector-load alignment requirement
+  int default_schedule;    // measured best schedule for this instantiation (PFB_OPT_SCHEDULE = -1)
 };
 const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt);
 

@@ -682,12 +682,12 @@ hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s) {
 template <class K>
 hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   if (p.frames <= 0) return hipSuccess;
-  if constexpr (K::NT == 64 && K::D == K::M) {
+  if constexpr (K::NT == 64) {
     if (p.schedule == 3) {  // shared-halo sliding windows: tile_waves runs of frames_per_block frames
       const int key = p.tile_waves * 1000 + p.frames_per_block;
       if (key == 8024) return launch_shared<K, 8, 24>(p, s);
       if (key == 8032) return launch_shared<K, 8, 32>(p, s);
-      if constexpr (K::FMT == PFB_FMT_INT16_IQ) {  // tuning sweep set (int16 only, keeps build time sane)
+      if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64) {  // tuning sweep set (cfg2 only, keeps build time sane)
         switch (key) {
           case 4032: return launch_shared<K, 4, 32>(p, s);
           case 4024: return launch_shared<K, 4, 24>(p, s);

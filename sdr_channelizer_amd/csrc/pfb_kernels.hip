@@ -190,20 +190,29 @@ hipError_t launch_stream_copy(const void* in, void* out, long long n_vec16, hipS
 using Cfg64x12i16 = FastCfg<64, 12, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
 using Cfg64x12i8  = FastCfg<64, 12, 64, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
 using Cfg64x12f32 = FastCfg<64, 12, 64, 1, PFB_FMT_CF32,     8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
+// cfg5: 2x oversampled, 24 taps per column, 128 = 16 x 8 (final-pass LDS reads are 2-way conflicted:
+// no single frame stride serves both passes, tools/fft_plan_model.py)
+using Cfg128x12os2i16 = FastCfg<128, 12, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 16, 8, 1, 8, 17, 0, 136, false, 2>;
+// cfg3: 4 adjacent columns per lane (8-byte loads of int8 I/Q), 256 = 16 x 16, conflict-free
+using Cfg256x8i8  = FastCfg<256, 8, 256, 4, PFB_FMT_INT8_IQ,  4, 2, 16, 16, 1, 16, 17, 0, 272, false, 2>;
+using Cfg256x8i16 = FastCfg<256, 8, 256, 4, PFB_FMT_INT16_IQ, 4, 2, 16, 16, 1, 16, 17, 0, 272, false, 2>;
 
 struct FastEntry { int M, P, D, fmt; FastKernelInfo info; };
 
 template <class K>
-constexpr FastEntry entry(const char* name, int default_fpb) {
+constexpr FastEntry entry(const char* name, int default_fpb, int default_schedule) {
   return FastEntry{K::M, K::P, K::D, K::FMT,
                    FastKernelInfo{&launch_fast<K>, &init_tables<K>, K::TAPS_LANE_FLOATS, K::TW_LANE_ELEMS, name, K::C,
-                                  default_fpb, K::CPT}};
+                                  default_fpb, K::CPT, default_schedule}};
 }
 
 static const FastEntry kFastTable[] = {
-    entry<Cfg64x12i16>("pfb_fast<M64,P12,D64,int16>", 512),
-    entry<Cfg64x12i8>("pfb_fast<M64,P12,D64,int8>", 512),
-    entry<Cfg64x12f32>("pfb_fast<M64,P12,D64,cf32>", 512),
+    entry<Cfg64x12i16>("pfb_fast<M64,P12,D64,int16>", 512, 3),
+    entry<Cfg64x12i8>("pfb_fast<M64,P12,D64,int8>", 512, 3),
+    entry<Cfg64x12f32>("pfb_fast<M64,P12,D64,cf32>", 512, 3),
+    entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 512, 0),
+    entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 256, 0),
+    entry<Cfg256x8i16>("pfb_fast<M256,P8,D256,int16>", 256, 0),
 };
 
 const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt) {

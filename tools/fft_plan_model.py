@@ -106,6 +106,8 @@ def check_conflicts(M, R, RS, FS, C, NT):
 PLANS = {
     # name: (M, R, RS, FS, C, NT)
     "m64": (64, [8, 8], [8, 9], 72, 8, 64),
+    "m128": (128, [16, 8], [8, 17], 136, 8, 64),     # final-pass reads 2-way
+    "m256": (256, [16, 16], [16, 17], 272, 4, 64),
 }
 
 if __name__ == "__main__":
