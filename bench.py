@@ -87,6 +87,7 @@ def main() -> None:
     ap.add_argument("--tile-waves", type=int, default=-1)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
     import torch
@@ -101,11 +102,16 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if os.environ.get("PFB_BENCH_ONE_DEVICE"):  # rehearsal on a 1-GPU box: every rank shares device 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     M, P, D, fmt, bw, bytes_in = WORKLOADS[args.workload]
     n = 1 << args.log2_samples

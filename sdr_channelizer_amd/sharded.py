@@ -28,18 +28,30 @@ def exchange_halo(tail, halo_out, rank: int, world: int, group=None, ring: bool 
     """Send ``tail`` (my segment's last history_samples samples) to rank+1 and receive the
     previous rank's into ``halo_out``.  With ring=False rank 0 receives nothing (stream start:
     its state stays as it is) and the last rank sends nothing."""
+    import torch
     import torch.distributed as dist
     if world == 1:
         return halo_out
+    # RCCL has no 16-bit integer type and gloo cannot touch device memory: ship raw bytes, and for
+    # gloo stage them on the host.
+    on_host = dist.get_backend(group) == "gloo" and tail.is_cuda
+    snd = tail.contiguous().view(torch.uint8).reshape(-1)
+    rcv = halo_out.view(torch.uint8).reshape(-1)
+    if on_host:
+        snd, rcv_dev, rcv = snd.cpu(), rcv, torch.empty(rcv.numel(), dtype=torch.uint8)
     ops = []
     nxt, prv = (rank + 1) % world, (rank - 1) % world
-    if ring or rank + 1 < world:
-        ops.append(dist.P2POp(dist.isend, tail, nxt, group))
-    if ring or rank > 0:
-        ops.append(dist.P2POp(dist.irecv, halo_out, prv, group))
+    sending = ring or rank + 1 < world
+    receiving = ring or rank > 0
+    if sending:
+        ops.append(dist.P2POp(dist.isend, snd, nxt, group))
+    if receiving:
+        ops.append(dist.P2POp(dist.irecv, rcv, prv, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    if on_host and receiving:
+        rcv_dev.copy_(rcv)
     return halo_out
 
 
