@@ -80,6 +80,7 @@ struct pfb_handle {
   int64_t opt_host_chunk = 0;
   int opt_nontemporal = 0;
   int opt_xcd_remap = 1;
+  int opt_experiment = 0;
   int opt_schedule = -1;  // -1: the instantiation's measured default
   int opt_grid = 0;
   int opt_tile_waves = 8;
@@ -138,6 +139,7 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
     p.flags = h->flags;
     p.nontemporal = h->opt_nontemporal;
     p.xcd_remap = h->opt_xcd_remap;
+    p.experiment = h->opt_experiment;
     p.grid_override = h->opt_grid;
     p.tile_waves = h->opt_tile_waves;
     const bool want_fast = h->fast && h->layout == PFB_LAYOUT_FRAME_MAJOR && h->opt_kernel != 1;
@@ -542,7 +544,11 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_grid = (int)value;
       return PFB_OK;
     case PFB_OPT_XCD_REMAP:
-      h->opt_xcd_remap = value ? 1 : 0;
+      if (value < 0 || value > (1 << 20)) return PFB_ERR_BAD_ARG;
+      h->opt_xcd_remap = (int)value;
+      return PFB_OK;
+    case PFB_OPT_EXPERIMENT:
+      h->opt_experiment = (int)value;
       return PFB_OK;
     case PFB_OPT_PROFILE:
       h->opt_profile = value ? 1 : 0;

@@ -35,7 +35,8 @@ struct KernelParams {
   int layout;              // pfb_output_layout
   unsigned flags;          // PFB_FLAG_*
   int nontemporal;         // nontemporal output stores
-  int xcd_remap;           // fast kernels: consecutive runs on one XCD
+  int xcd_remap;           // fast kernels: 1 = consecutive runs on one XCD, G>1 = in groups of G
+  int experiment;          // bit mask of timing experiments (0 in production)
   int schedule;            // fast kernels: 0 = sliding-window runs, 1 = persistent strided chunks,
                            //               2 = one chunk per wave, tile_waves chunks per workgroup
   int tile_waves;          // schedule 2: waves (= adjacent chunks) per workgroup: 1, 2, 4, 8 or 16

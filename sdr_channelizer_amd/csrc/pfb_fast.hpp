@@ -156,7 +156,7 @@ template <int N> struct Dft {
 // Kernel configuration
 
 template <int M_, int P_, int D_, int CPT_, int FMT_, int C_, int NP_, int R0_, int R1_, int R2_, int RS0_,
-          int RS1_, int RS2_, int FS_, bool PINGPONG_, int MIN_WAVES_>
+          int RS1_, int RS2_, int FS_, bool PINGPONG_, int MIN_WAVES_, bool TW_TABLE_ = false>
 struct FastCfg {
   static constexpr int M = M_, P = P_, D = D_, CPT = CPT_, FMT = FMT_, C = C_, NP = NP_;
   static constexpr int NT = D / CPT;   // threads per workgroup
@@ -164,6 +164,8 @@ struct FastCfg {
   static constexpr int OS = M / D;     // branches per column (1, or 2 when oversampled)
   static constexpr int FS = FS_;       // frame stride in LDS (complex elements)
   static constexpr bool PINGPONG = PINGPONG_;
+  static constexpr bool TW_TABLE = TW_TABLE_;  // inter-pass twiddles re-read from the L1-resident table
+                                               // every chunk instead of living in registers
   static constexpr int MIN_WAVES = MIN_WAVES_;
   static constexpr int R(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : R2_; }
   static constexpr int RS(int i) { return i == 0 ? RS0_ : i == 1 ? RS1_ : RS2_; }
@@ -180,9 +182,10 @@ struct FastCfg {
   static_assert(NP >= 2 && NP <= 3, "2 or 3 passes");
   static_assert(R0_ * R1_ * (NP_ == 3 ? R2_ : 1) == M_, "radices multiply to M");
   static_assert(R(0) * RS(0) <= FS && R(1) * RS(1) <= FS && (NP < 3 || R(2) * RS(2) <= FS), "frame fits");
-  // in-place passes are only safe when one wave does the whole pass in one go
-  static_assert(PINGPONG || (NT == 64 && C * (M / R(0)) <= 64 && (NP < 3 || C * (M / R(1)) <= 64)),
-                "multi-wave or multi-iteration non-final passes need ping-pong buffers");
+  // in-place non-final passes need every read of the pass to precede every write: one iteration per
+  // thread, and (multi-wave teams) a barrier between the reads and the writes
+  static_assert(PINGPONG || (C * (M / R(0)) <= NT && (NP < 3 || C * (M / R(1)) <= NT)),
+                "multi-iteration non-final passes need ping-pong buffers");
 };
 
 // ---------------------------------------------------------------------------------
@@ -209,7 +212,18 @@ struct FastKernel {
   PFB_DEV void load_row(const KernelParams& p, const raw_t* run_ptr, long long r, long long r_rel, int c0,
                         raw_t (&raw)[CPT]) {
     if constexpr (INTERIOR) {
-      const RawVec v = *reinterpret_cast<const RawVec*>(run_ptr + r_rel * D + c0);
+      const RawVec* vp = reinterpret_cast<const RawVec*>(run_ptr + r_rel * D + c0);
+      RawVec v;
+      if constexpr (sizeof(RawVec) == 4) {
+        if (p.experiment & 1) {  // streaming (nontemporal) row loads
+          const uint32_t u = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(vp));
+          __builtin_memcpy(&v, &u, 4);
+        } else {
+          v = *vp;
+        }
+      } else {
+        v = *vp;
+      }
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) raw[cc] = v.v[cc];
     } else {
@@ -235,7 +249,8 @@ struct FastKernel {
     constexpr int R = K::R(I), S = K::S(I), KK = K::K(I), RS = K::RS(I);
     constexpr int IPF = M / R, ITEMS = C * IPF, ITERS = (ITEMS + NT - 1) / NT;
     constexpr bool LAST = (I == K::NP - 1);
-    constexpr bool TW_REGS = (ITERS == 1);
+    constexpr bool TW_REGS = (ITERS == 1) && !K::TW_TABLE;
+    constexpr bool READ_BARRIER = !LAST && !K::PINGPONG && NT > 64;  // in place across several waves
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int w = tid + it * NT;
@@ -251,16 +266,22 @@ struct FastKernel {
 #pragma unroll
         for (int n = 0; n < R; ++n) x[n] = (v2f){0.f, 0.f};
       }
+      if constexpr (READ_BARRIER) __syncthreads();
       Dft<R>::run(x);
       if constexpr (!LAST) {
         constexpr int S1 = K::S(I + 1), RS1 = K::RS(I + 1);
-        // twiddle e^{+j 2 pi rest k / (R S)} = tw[rest * k * KK]
+        // twiddle e^{+j 2 pi rest k / (R S)}: row `rest` of this pass's table
+        if constexpr (TW_REGS) {
 #pragma unroll
-        for (int k = 1; k < R; ++k) {
-          v2f wk;
-          if constexpr (TW_REGS) wk = tw[I][k];
-          else { const float2 t = p.tw[rest * k * KK]; wk = (v2f){t.x, t.y}; }
-          x[k] = cmul_w(x[k], wk);
+          for (int k = 1; k < R; ++k) x[k] = cmul_w(x[k], tw[I][k]);
+        } else {
+          const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(I) + rest * R);
+#pragma unroll
+          for (int k2 = 0; k2 < R / 2; ++k2) {
+            const float4 t = t4[k2];
+            if (k2 > 0) x[2 * k2] = cmul_w(x[2 * k2], (v2f){t.x, t.y});
+            x[2 * k2 + 1] = cmul_w(x[2 * k2 + 1], (v2f){t.z, t.w});
+          }
         }
         const int n1 = rest / S1, rest2 = rest % S1;
         if (active) {
@@ -317,7 +338,7 @@ struct FastKernel {
     for (int i = 0; i < K::NP - 1; ++i) {
       constexpr int dummy = 0; (void)dummy;
       const int R = K::R(i), S = K::S(i), IPF = M / R;
-      if (C * IPF <= NT) {
+      if (C * IPF <= NT && !K::TW_TABLE) {
         const int rest = (tid % IPF) % S;
         const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(i) + rest * R);
 #pragma unroll
@@ -502,9 +523,18 @@ struct FastKernel {
     static_assert(NT == 64, "one wave per run");
     const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
     long long blk = blockIdx.x;
-    if (p.xcd_remap) {
+    if (p.xcd_remap == 1) {
       const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = blk & 7;
       blk = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (blk >> 3);
+    } else if (p.xcd_remap > 1) {
+      // grouped remap: each XCD takes G consecutive blocks at a time (G = xcd_remap): one sweeping
+      // window for the whole chip, boundary halos still mostly on one XCD.  Tail blocks unmapped.
+      const long long G = p.xcd_remap, span = 8 * G, nb = gridDim.x;
+      const long long base = (blk / span) * span;
+      if (base + span <= nb) {
+        const long long in = blk - base, xc = in & 7, idx = in >> 3;
+        blk = base + xc * G + idx;
+      }
     }
     const long long f_blk = blk * (long long)(NWV * L);
     const long long f_begin = f_blk + (long long)wave * L;
@@ -720,7 +750,7 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       }
     }
   }
-  if (p.schedule == 1) {  // persistent strided chunks
+  if (K::NT == 64 && p.schedule == 1) {  // persistent strided chunks
     static int resident = 0;  // workgroups resident at once on this device class
     if (resident == 0) {
       int per_cu = 0, dev = 0;

@@ -197,6 +197,11 @@ using Cfg128x12os2i16 = FastCfg<128, 12, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 16, 8, 1
 using Cfg256x8i8  = FastCfg<256, 8, 256, 4, PFB_FMT_INT8_IQ,  4, 2, 16, 16, 1, 16, 17, 0, 272, false, 2>;
 using Cfg256x8i16 = FastCfg<256, 8, 256, 4, PFB_FMT_INT16_IQ, 4, 2, 16, 16, 1, 16, 17, 0, 272, false, 2>;
 
+// cfg4: 512 threads x 2 adjacent columns (8-byte loads), 1024 = 16 x 16 x 4 in place in one 68 KB chunk
+// buffer (read - barrier - write), twiddles from the L1-resident table, conflict-free padding
+using Cfg1024x16i16 =
+    FastCfg<1024, 16, 1024, 2, PFB_FMT_INT16_IQ, 8, 3, 16, 16, 4, 64, 68, 260, 1088, false, 2, true>;
+
 struct FastEntry { int M, P, D, fmt; FastKernelInfo info; };
 
 template <class K>
@@ -213,6 +218,7 @@ static const FastEntry kFastTable[] = {
     entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 512, 0),
     entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 256, 0),
     entry<Cfg256x8i16>("pfb_fast<M256,P8,D256,int16>", 256, 0),
+    entry<Cfg1024x16i16>("pfb_fast<M1024,P16,D1024,int16>", 256, 0),
 };
 
 const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt) {

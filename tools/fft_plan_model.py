@@ -108,6 +108,7 @@ PLANS = {
     "m64": (64, [8, 8], [8, 9], 72, 8, 64),
     "m128": (128, [16, 8], [8, 17], 136, 8, 64),     # final-pass reads 2-way
     "m256": (256, [16, 16], [16, 17], 272, 4, 64),
+    "m1024": (1024, [16, 16, 4], [64, 68, 260], 1088, 8, 512),
 }
 
 if __name__ == "__main__":
