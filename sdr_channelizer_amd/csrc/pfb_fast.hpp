@@ -705,7 +705,9 @@ template <class K, int NWV, int L>
 hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s) {
   const long long per = (long long)NWV * L;
   const long long blocks = (p.frames + per - 1) / per;
-  hipLaunchKernelGGL((pfb_shared_kernel<K, NWV, L>), dim3((unsigned)blocks), dim3(64 * NWV), 0, s, p);
+  // experiment bits 8.. : extra dynamic LDS in KiB (occupancy throttle for access-window studies)
+  const unsigned extra_lds = (unsigned)((p.experiment >> 8) & 0xff) * 1024u;
+  hipLaunchKernelGGL((pfb_shared_kernel<K, NWV, L>), dim3((unsigned)blocks), dim3(64 * NWV), extra_lds, s, p);
   return hipGetLastError();
 }
 
