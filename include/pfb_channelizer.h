@@ -194,6 +194,41 @@ const char* pfb_last_kernel(const pfb_handle* h);
  * roofline.  Uses `bytes_in` of input and 2*bytes_in of output scratch. */
 int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double* bytes_per_sec);
 
+/* ---- channelized PDW extraction ------------------------------------------------
+ * Replaces the second half of matlab/create_pdws_channelized.m (lines 64-143): per-channel
+ * noise floor = median magnitude (:73), threshold NF*10^(SNR_THRESHOLD/10) (:74-75), the
+ * leading/trailing-edge state machine over frames (:85-135), and per pulse the median
+ * magnitude (:101), SNR (:105), pulse width (:110), median wrapped phase step -> frequency
+ * (:114-122) and the saturation flag (:130-132).  Input is the F x M matrix the channelizer
+ * produced (frame-major complex64, already fftshift-ed as in :60), on the GPU or the host.
+ * PDWs come back in the reference's order: channels outermost, time within a channel. */
+typedef struct pfb_pdw {
+  double toa;   /* UTC seconds: (1-based frame index)/fs + sample_start_time (:98)        */
+  double freq;  /* Hz (:122)                                                             */
+  double pw;    /* seconds (:110)                                                        */
+  double snr;   /* dB (:105)                                                             */
+  int32_t sat;  /* 0/1 (:130-132)                                                        */
+  int32_t bin;  /* 0-based (shifted) column the pulse was found in                       */
+} pfb_pdw;
+
+enum {
+  /* reproduce the reference's two indexing quirks: the unshifted centre-frequency list is
+   * indexed with the shifted column (:42 vs :80) and phase(toa:jj) linear-indexes column 1
+   * (:114).  Without the flag the pulse's own column and its true centre frequency are used. */
+  PFB_PDW_MATLAB_QUIRKS = 1u << 0
+};
+
+/* fs_in: sample rate BEFORE decimation; the frame rate used is fs_in/decimation (:62).
+ * noise_floor_out (optional, M doubles): the per-channel medians.  *count receives the number
+ * of pulses found even when it exceeds capacity (only `capacity` are written).
+ * mem: PFB_MEM_HOST / PFB_MEM_DEVICE for `y`; `out` and `noise_floor_out` are host memory. */
+int pfb_pdw_extract(const void* y, uint64_t frames, uint32_t num_channels, uint32_t decimation,
+                    double fs_in, double fc, double sample_start_time, double snr_threshold_db,
+                    uint32_t flags, pfb_pdw* out, uint64_t capacity, uint64_t* count,
+                    double* noise_floor_out, uint32_t mem, int32_t device_id, void* hip_stream);
+/* Text of the most recent HIP failure inside pfb_pdw_extract on this thread. */
+const char* pfb_pdw_last_error_detail(void);
+
 #ifdef __cplusplus
 }
 #endif

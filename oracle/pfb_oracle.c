@@ -408,11 +408,11 @@ static double median_of(double* tmp, size_t n) {
   return (n & 1) ? tmp[n / 2] : 0.5 * (tmp[n / 2 - 1] + tmp[n / 2]);
 }
 
-size_t pfbo_extract_pdws(const double* yr, const double* yi, size_t F, int M,
+size_t pfbo_extract_pdws(const double* yr, const double* yi, size_t F, int M, int decim,
                          double fs_in, double fc, double sample_start_time,
                          double snr_threshold_db, int matlab_quirks,
                          pfbo_pdw* out, size_t max_out) {
-  const double fs = fs_in / (double)M; /* :62 */
+  const double fs = fs_in / (double)decim; /* :62 (decim = M in the reference) */
   double* tmp = (double*)malloc(sizeof(double) * (F + 1));
   double* nf = (double*)malloc(sizeof(double) * (size_t)M * 2);
   double* bin_freqs = nf + M;

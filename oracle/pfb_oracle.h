@@ -135,13 +135,14 @@ typedef struct {
 } pfbo_pdw;
 
 /* y: F x M complex, frame-major, already fftshift-ed (:60). fs_in is the rate
- * BEFORE decimation, decim = M (fs <- fs/M, :62). bin_freqs are the UNSHIFTED
+ * BEFORE decimation; the reference divides by M (fs <- fs/M, :62); decim carries the true
+ * decimation so the 2x oversampled bank (decim = M/2) gets its real frame rate. bin_freqs are the UNSHIFTED
  * centre frequencies indexed with the SHIFTED column number exactly as the
  * reference does (:42 vs :60,:80) when matlab_quirks != 0; otherwise the
  * shifted (correct) centre frequency is used and phase(toa:jj) is taken from
  * the pulse's own column instead of column 1 (:114).
  * Returns the number of PDWs found; writes at most max_out of them. */
-size_t pfbo_extract_pdws(const double* yr, const double* yi, size_t F, int M,
+size_t pfbo_extract_pdws(const double* yr, const double* yi, size_t F, int M, int decim,
                          double fs_in, double fc, double sample_start_time,
                          double snr_threshold_db, int matlab_quirks,
                          pfbo_pdw* out, size_t max_out);

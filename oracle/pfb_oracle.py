@@ -104,7 +104,7 @@ class COracle:
         lib.pfbo_parse_iq_header.restype = C.c_int
         lib.pfbo_parse_iq_header.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_IqHeader)]
         lib.pfbo_extract_pdws.restype = C.c_size_t
-        lib.pfbo_extract_pdws.argtypes = [_dp, _dp, C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_double,
+        lib.pfbo_extract_pdws.argtypes = [_dp, _dp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                           C.c_double, C.c_int, C.POINTER(_Pdw), C.c_size_t]
 
     # -- a3 -------------------------------------------------------------------
@@ -178,13 +178,14 @@ class COracle:
         return d
 
     def extract_pdws(self, y: np.ndarray, fs_in: float, fc: float, start_time: float,
-                     snr_db: float = 15.0, matlab_quirks: bool = True, max_out: int = 1 << 16):
+                     snr_db: float = 15.0, matlab_quirks: bool = True, max_out: int = 1 << 16, decim: int | None = None):
         y = np.asarray(y, dtype=np.complex128)
         F, M = y.shape
         yr = np.ascontiguousarray(y.real).reshape(-1)
         yi = np.ascontiguousarray(y.imag).reshape(-1)
         buf = (_Pdw * max_out)()
-        n = self.lib.pfbo_extract_pdws(yr, yi, F, M, fs_in, fc, start_time, snr_db, int(matlab_quirks), buf, max_out)
+        n = self.lib.pfbo_extract_pdws(yr, yi, F, M, M if decim is None else decim, fs_in, fc, start_time, snr_db,
+                                       int(matlab_quirks), buf, max_out)
         n = min(int(n), max_out)
         return [dict(toa=b.toa, freq=b.freq, pw=b.pw, snr=b.snr, sat=bool(b.sat), bin=b.bin) for b in buf[:n]]
 

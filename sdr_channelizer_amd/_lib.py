@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C  # noqa: N811
 import os
+import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpfb_channelizer.so")
@@ -47,6 +48,14 @@ class PfbIqPacket(C.Structure):
     ]
 
 
+class PfbPdw(C.Structure):
+    _fields_ = [("toa", C.c_double), ("freq", C.c_double), ("pw", C.c_double), ("snr", C.c_double),
+                ("sat", C.c_int32), ("bin", C.c_int32)]
+
+
+PFB_PDW_MATLAB_QUIRKS = 1
+
+
 class PfbIqInfo(C.Structure):
     _fields_ = [
         ("packet", PfbIqPacket), ("file_format", C.c_int32), ("header_bytes", C.c_uint32),
@@ -60,7 +69,8 @@ EXPORTS = (
     "pfb_frames_for", "pfb_history_samples", "pfb_prime", "pfb_get_state", "pfb_set_state", "pfb_set_frame_index",
     "pfb_get_frame_index", "pfb_center_frequencies", "pfb_design_prototype", "pfb_strerror",
     "pfb_last_error_detail", "pfb_abi_version", "pfb_device_count", "pfb_set_option", "pfb_last_kernel",
-    "pfb_measure_stream_copy", "pfb_get_kernel_times", "pfb_iq_parse_header", "pfb_iq_fill_packet", "pfb_iq_filename",
+    "pfb_measure_stream_copy", "pfb_get_kernel_times", "pfb_pdw_extract", "pfb_pdw_last_error_detail",
+    "pfb_iq_parse_header", "pfb_iq_fill_packet", "pfb_iq_filename",
 )
 
 _lib = None
@@ -79,6 +89,14 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own libamdhip64; two HIP runtimes in one process cannot both own the
+    # GPU ("No HIP GPUs are available" for whichever comes second).  If PyTorch is installed, let it
+    # load its runtime first: our library's libamdhip64.so.7 dependency then binds to that same copy,
+    # and torch tensors / streams can be handed straight to the C ABI.
+    if "torch" not in sys.modules and os.environ.get("PFB_NO_TORCH_PRELOAD") is None:
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m sdr_channelizer_amd.build` "
@@ -109,6 +127,9 @@ def load() -> C.CDLL:
     lib.pfb_last_kernel.argtypes = [vp]
     lib.pfb_last_kernel.restype = C.c_char_p
     lib.pfb_get_kernel_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+    lib.pfb_pdw_extract.argtypes = [vp, u64, u32, u32, C.c_double, C.c_double, C.c_double, C.c_double, u32,
+                                    C.POINTER(PfbPdw), u64, C.POINTER(u64), C.POINTER(C.c_double), u32, i32, vp]
+    lib.pfb_pdw_last_error_detail.restype = C.c_char_p
     lib.pfb_measure_stream_copy.argtypes = [C.c_int, u64, C.c_int, C.POINTER(C.c_double)]
     lib.pfb_iq_parse_header.argtypes = [vp, C.c_size_t, C.POINTER(PfbIqInfo)]
     lib.pfb_iq_fill_packet.argtypes = [C.POINTER(PfbIqPacket), u32, u64, u32, u32, C.c_float, u32, u32,

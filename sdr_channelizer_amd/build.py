@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libpfb_channelizer.so")
-SOURCES = ["pfb_api.cpp", "pfb_kernels.hip", "iq_packet.c"]
+SOURCES = ["pfb_api.cpp", "pfb_kernels.hip", "pfb_pdw.hip", "iq_packet.c"]
 HEADERS = ["pfb_common.h", "pfb_fast.hpp"]
 ARCH = "gfx950"
 
