@@ -52,8 +52,8 @@ class Channelizer:
     def __init__(self, num_bands: int, *, taps: np.ndarray | None = None, taps_per_band: int = 12,
                  stopband_atten: float = 80.0, decimation: int | None = None, sample_format: str = "int16",
                  bit_width: int = 12, channel_major: bool = False, fftshift: bool = False,
-                 conjugate_input: bool = False, derotate: bool = False, input_offset: int = -1,
-                 device: int = -1):
+                 conjugate_input: bool = False, derotate: bool = False, magnitude: bool = False,
+                 input_offset: int = -1, device: int = -1):
         self._h = C.c_void_p()
         lib = L.load()
         M = int(num_bands)
@@ -70,8 +70,9 @@ class Channelizer:
         self.bit_width = int(bit_width)
         self.channel_major = bool(channel_major)
         self.device = device
+        self.magnitude = bool(magnitude)  # fused abs(channelizer(x)): float32 out
         flags = (L.PFB_FLAG_FFTSHIFT if fftshift else 0) | (L.PFB_FLAG_CONJUGATE_INPUT if conjugate_input else 0) \
-            | (L.PFB_FLAG_DEROTATE if derotate else 0)
+            | (L.PFB_FLAG_DEROTATE if derotate else 0) | (L.PFB_FLAG_MAGNITUDE if magnitude else 0)
         cfg = L.PfbConfig(C.sizeof(L.PfbConfig), M, self.taps_per_band, self.decimation,
                           taps.ctypes.data_as(C.POINTER(C.c_float)), self.fmt, self.bit_width,
                           L.PFB_LAYOUT_CHANNEL_MAJOR if channel_major else L.PFB_LAYOUT_FRAME_MAJOR, flags,
@@ -175,10 +176,11 @@ class Channelizer:
             n = iq.numel() if iq.is_complex() else iq.numel() // 2
             F = self.frames_for(n)
             shape = (M, F) if self.channel_major else (F, M)
+            odt = torch.float32 if self.magnitude else torch.complex64
             if out is None:
-                out = torch.empty(shape, dtype=torch.complex64, device=iq.device)
-            elif out.numel() < F * M or out.dtype != torch.complex64 or not out.is_contiguous():
-                raise ValueError("out must be a contiguous complex64 tensor with room for frames*M values")
+                out = torch.empty(shape, dtype=odt, device=iq.device)
+            elif out.numel() < F * M or out.dtype != odt or not out.is_contiguous():
+                raise ValueError(f"out must be a contiguous {odt} tensor with room for frames*M values")
             f = C.c_uint64()
             fn = self._lib.pfb_process if sync else self._lib.pfb_process_async
             args = [self._h, C.c_void_p(iq.data_ptr()), n, C.c_void_p(out.data_ptr()), F, C.byref(f)]
@@ -189,7 +191,7 @@ class Channelizer:
         a, n = self._host_samples(iq)
         F = self.frames_for(n)
         shape = (M, F) if self.channel_major else (F, M)
-        res = np.empty(shape, dtype=np.complex64) if out is None else out
+        res = np.empty(shape, dtype=np.float32 if self.magnitude else np.complex64) if out is None else out
         f = C.c_uint64()
         L.check(self._lib.pfb_process(self._h, C.c_void_p(a.ctypes.data), n, C.c_void_p(res.ctypes.data), F,
                                       C.byref(f), L.PFB_MEM_HOST), "pfb_process")

@@ -63,6 +63,7 @@ struct pfb_handle {
   unsigned flags = 0;
   int device = 0;
   int bps = 0;             // bytes per input sample
+  int out_elem = 8;        // bytes per output element: complex64, or float32 with PFB_FLAG_MAGNITUDE
   int hist_samples = 0;    // M*P + D
   float* d_taps = nullptr;   // M*P, scaled by 2^-(bit_width-1)
   float2* d_tw = nullptr;    // M
@@ -220,11 +221,11 @@ int process_host(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t 
     if (rc2 != PFB_OK) return rc2;
     if (f > 0) {
       if (h->layout == PFB_LAYOUT_FRAME_MAJOR) {
-        HIP_TRY(hipMemcpyAsync(dst + frames_done * h->M * sizeof(float2), h->d_stage_out,
-                               (size_t)f * h->M * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(dst + frames_done * h->M * h->out_elem, h->d_stage_out,
+                               (size_t)f * h->M * h->out_elem, hipMemcpyDeviceToHost, h->stream));
       } else {  // column k of this chunk -> rows [frames_done, frames_done+f) of column k of the call
-        HIP_TRY(hipMemcpy2DAsync(dst + frames_done * sizeof(float2), (size_t)frames_total * sizeof(float2),
-                                 h->d_stage_out, (size_t)f * sizeof(float2), (size_t)f * sizeof(float2),
+        HIP_TRY(hipMemcpy2DAsync(dst + frames_done * h->out_elem, (size_t)frames_total * h->out_elem,
+                                 h->d_stage_out, (size_t)f * h->out_elem, (size_t)f * h->out_elem,
                                  (size_t)h->M, hipMemcpyDeviceToHost, h->stream));
       }
     }
@@ -337,6 +338,7 @@ int pfb_create(const pfb_config* cfg, pfb_handle** out) {
   h->M = (int)M; h->P = (int)P; h->D = (int)D; h->off = off;
   h->fmt = (int)cfg->sample_format; h->bit_width = bw; h->layout = (int)cfg->output_layout;
   h->flags = cfg->flags;
+  h->out_elem = (cfg->flags & PFB_FLAG_MAGNITUDE) ? 4 : 8;
   h->device = dev;
   h->bps = pfb::bytes_per_sample(h->fmt);
   h->hist_samples = (int)(M * P + D);

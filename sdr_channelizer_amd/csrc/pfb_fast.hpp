@@ -294,13 +294,22 @@ struct FastKernel {
         if (active && f < p.frames) {
           const bool flip_odd = (OS == 2) && (p.flags & PFB_FLAG_DEROTATE) && ((p.frame0 + f) & 1);
           const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
-          float2* row = p.out + f0 * M + fc * M;
+          if (p.flags & PFB_FLAG_MAGNITUDE) {  // fused abs(): 4 bytes per channel instead of 8
+            float* rowm = reinterpret_cast<float*>(p.out) + f0 * M + fc * M;
 #pragma unroll
-          for (int k = 0; k < R; ++k) {
-            const int ch = kk + k * KK;
-            v2f v = x[k];
-            if (flip_odd && (ch & 1)) v = -v;
-            store_c64(&row[ch ^ shift], v, p.nontemporal);
+            for (int k = 0; k < R; ++k) {
+              const int ch = kk + k * KK;
+              rowm[ch ^ shift] = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
+            }
+          } else {
+            float2* row = p.out + f0 * M + fc * M;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+              const int ch = kk + k * KK;
+              v2f v = x[k];
+              if (flip_odd && (ch & 1)) v = -v;
+              store_c64(&row[ch ^ shift], v, p.nontemporal);
+            }
           }
         }
       }

@@ -290,3 +290,20 @@ def test_every_schedule_gives_identical_bits(oracle, opts):
     want = oracle_run(oracle, iq, h, M, P, M, 12)
     assert rel(ref, want) < REL_TOL
     assert np.array_equal(np.concatenate([got, got2]), ref)
+
+
+@pytest.mark.parametrize("M,P,D,fmt,bw,kw", [(64, 12, 64, "int16", 12, {}), (128, 12, 64, "int16", 12, {}),
+                                             (256, 8, 256, "int8", 8, {}), (1024, 16, 1024, "int16", 16, {}),
+                                             (56, 12, 56, "int16", 12, {}), (64, 12, 64, "int16", 12, dict(channel_major=True))])
+def test_fused_magnitude_output(oracle, M, P, D, fmt, bw, kw):
+    """PFB_FLAG_MAGNITUDE = abs(channelizer(x)) of channelizer_example.m:56, fused into the store."""
+    n = D * 300
+    iq = synth.pulsed_iq_numpy(n, bw, np.int8 if fmt == "int8" else np.int16, seed=17)
+    h = oracle.design_prototype(M, P).astype(np.float32)
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, magnitude=True, fftshift=True, **kw) as ch:
+        m = ch(iq)
+    want = np.abs(oracle_run(oracle, iq, h, M, P, D, bw, fftshift=True))
+    if kw.get("channel_major"):
+        m = m.T
+    assert m.dtype == np.float32 and m.shape == want.shape
+    assert np.abs(m - want).max() / want.max() < REL_TOL

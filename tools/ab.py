@@ -27,6 +27,7 @@ ap.add_argument("--log2-samples", type=int, default=30)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--workload", default="64,12,64,int16,12")
+ap.add_argument("--magnitude", action="store_true")
 ap.add_argument("cases", nargs="+")
 a = ap.parse_args()
 
@@ -35,8 +36,8 @@ M, P, D, bw = int(M), int(P), int(D), int(bw)
 n = 1 << a.log2_samples
 dev = torch.device("cuda", 0)
 iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device=dev)
-out = torch.empty((n // D, M), dtype=torch.complex64, device=dev)
-ch = Channelizer(M, taps=design_prototype(M, P), decimation=D, sample_format=fmt, bit_width=bw)
+out = torch.empty((n // D + 1, M), dtype=torch.float32 if a.magnitude else torch.complex64, device=dev)
+ch = Channelizer(M, taps=design_prototype(M, P), decimation=D, sample_format=fmt, bit_width=bw, magnitude=a.magnitude)
 ch.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 cases = []
 for c in a.cases:
@@ -47,7 +48,7 @@ for c in a.cases:
         opts[k] = int(v)
     cases.append((name, opts))
 times = {name: [] for name, _ in cases}
-bytes_per_sample = (2 if fmt == "int8" else 4) + 8 * (M // D)
+bytes_per_sample = (2 if fmt == "int8" else 4) + (4 if a.magnitude else 8) * (M // D)
 ch.set_option(L.PFB_OPT_PROFILE, 1)
 for r in range(a.rounds + 1):
     for name, opts in cases:
