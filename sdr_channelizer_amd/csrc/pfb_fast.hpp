@@ -133,6 +133,29 @@ template <> struct Dft<4> {
   }
 };
 
+// 7-point DFT (the reference's own band count is fs*1e-6 = 56 = 8 x 7, channelizer_example.m:29):
+// pair n with 7-n, X[k] = A_k + j B_k, X[7-k] = A_k - j B_k with
+// A_k = x0 + sum_n (x_n + x_{7-n}) cos(2 pi k n / 7),  B_k = sum_n (x_n - x_{7-n}) sin(2 pi k n / 7)
+template <> struct Dft<7> {
+  PFB_DEV void run(v2f (&x)[7]) {
+    constexpr float c1 = 0.62348980185873353f, c2 = -0.22252093395631440f, c3 = -0.90096886790241913f;
+    constexpr float s1 = 0.78183148246802981f, s2 = 0.97492791218182361f, s3 = 0.43388373911755812f;
+    const v2f p1 = x[1] + x[6], p2 = x[2] + x[5], p3 = x[3] + x[4];
+    const v2f d1 = x[1] - x[6], d2 = x[2] - x[5], d3 = x[3] - x[4];
+    const v2f x0 = x[0];
+    const v2f a1 = fma2(p3, splat(c3), fma2(p2, splat(c2), fma2(p1, splat(c1), x0)));
+    const v2f a2 = fma2(p3, splat(c1), fma2(p2, splat(c3), fma2(p1, splat(c2), x0)));
+    const v2f a3 = fma2(p3, splat(c2), fma2(p2, splat(c1), fma2(p1, splat(c3), x0)));
+    const v2f b1 = fma2(d3, splat(s3), fma2(d2, splat(s2), d1 * splat(s1)));
+    const v2f b2 = fma2(d3, splat(-s1), fma2(d2, splat(-s3), d1 * splat(s2)));
+    const v2f b3 = fma2(d3, splat(s2), fma2(d2, splat(-s1), d1 * splat(s3)));
+    x[0] = x0 + p1 + p2 + p3;
+    x[1] = add_j(a1, b1); x[6] = sub_j(a1, b1);
+    x[2] = add_j(a2, b2); x[5] = sub_j(a2, b2);
+    x[3] = add_j(a3, b3); x[4] = sub_j(a3, b3);
+  }
+};
+
 template <int N, int K>
 struct DftCombine {
   PFB_DEV void run(v2f (&x)[N], const v2f (&e)[N / 2], const v2f (&o)[N / 2]) {
@@ -159,7 +182,9 @@ template <int M_, int P_, int D_, int CPT_, int FMT_, int C_, int NP_, int R0_, 
           int RS1_, int RS2_, int FS_, bool PINGPONG_, int MIN_WAVES_, bool TW_TABLE_ = false>
 struct FastCfg {
   static constexpr int M = M_, P = P_, D = D_, CPT = CPT_, FMT = FMT_, C = C_, NP = NP_;
-  static constexpr int NT = D / CPT;   // threads per workgroup
+  static constexpr int LANES = D / CPT;                  // threads that own columns
+  static constexpr int NT = (LANES + 63) / 64 * 64;      // threads per workgroup (whole waves)
+  static constexpr bool POW2 = (M & (M - 1)) == 0;
   static constexpr int W = M * P / D;  // window rows = taps per column
   static constexpr int OS = M / D;     // branches per column (1, or 2 when oversampled)
   static constexpr int FS = FS_;       // frame stride in LDS (complex elements)
@@ -177,7 +202,8 @@ struct FastCfg {
   static constexpr int TW_LANE_ELEMS = TW_OFF(NP - 1) > 0 ? TW_OFF(NP - 1) : 1;  // inter-pass twiddle rows
   static constexpr int BUF = C * FS;   // one chunk buffer (complex elements)
   static constexpr int LDS_ELEMS = BUF * (PINGPONG ? 2 : 1);
-  static_assert(D % CPT == 0 && NT % 64 == 0, "whole waves");
+  static_assert(D % CPT == 0, "columns split evenly over threads");
+  static_assert(R(0) % 2 == 0 && (NP < 3 || R(1) % 2 == 0), "non-final radices are even (twiddle rows are float4s)");
   static_assert(M % D == 0 && (M * P) % D == 0, "D divides M");
   static_assert(NP >= 2 && NP <= 3, "2 or 3 passes");
   static_assert(R0_ * R1_ * (NP_ == 3 ? R2_ : 1) == M_, "radices multiply to M");
@@ -211,6 +237,11 @@ struct FastKernel {
   template <bool INTERIOR>
   PFB_DEV void load_row(const KernelParams& p, const raw_t* run_ptr, long long r, long long r_rel, int c0,
                         raw_t (&raw)[CPT]) {
+    if (K::LANES < NT && c0 >= D) {  // lanes beyond the last column (D not a multiple of 64)
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) raw[cc] = raw_t{};
+      return;
+    }
     if constexpr (INTERIOR) {
       const RawVec* vp = reinterpret_cast<const RawVec*>(run_ptr + r_rel * D + c0);
       RawVec v;
@@ -294,12 +325,17 @@ struct FastKernel {
         if (active && f < p.frames) {
           const bool flip_odd = (OS == 2) && (p.flags & PFB_FLAG_DEROTATE) && ((p.frame0 + f) & 1);
           const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
+          // fftshift(out,2): column (k + M/2) mod M; an XOR when M is a power of two
+          auto col_of = [&](int ch) {
+            if constexpr (K::POW2) return ch ^ shift;
+            else { const int c2 = ch + shift; return c2 >= M ? c2 - M : c2; }
+          };
           if (p.flags & PFB_FLAG_MAGNITUDE) {  // fused abs(): 4 bytes per channel instead of 8
             float* rowm = reinterpret_cast<float*>(p.out) + f0 * M + fc * M;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
               const int ch = kk + k * KK;
-              rowm[ch ^ shift] = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
+              rowm[col_of(ch)] = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
             }
           } else {
             float2* row = p.out + f0 * M + fc * M;
@@ -308,7 +344,7 @@ struct FastKernel {
               const int ch = kk + k * KK;
               v2f v = x[k];
               if (flip_odd && (ch & 1)) v = -v;
-              store_c64(&row[ch ^ shift], v, p.nontemporal);
+              store_c64(&row[col_of(ch)], v, p.nontemporal);
             }
           }
         }
@@ -334,7 +370,8 @@ struct FastKernel {
     const int c0 = tid * CPT;
 #pragma unroll
     for (int cc = 0; cc < CPT; ++cc) {
-      const float4* tl = reinterpret_cast<const float4*>(p.taps_lane + (size_t)(c0 + cc) * K::WP);
+      const int col = (K::LANES < NT && c0 >= D) ? 0 : c0 + cc;  // idle lanes read column 0's taps
+      const float4* tl = reinterpret_cast<const float4*>(p.taps_lane + (size_t)col * K::WP);
 #pragma unroll
       for (int q4 = 0; q4 < K::WP / 4; ++q4) {
         const float4 v = tl[q4];
@@ -392,9 +429,11 @@ struct FastKernel {
             else fma_tap_lo(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
           }
         }
+        if (!(K::LANES < NT) || tid < K::LANES) {
 #pragma unroll
-        for (int t = 0; t < C; ++t)
-          reinterpret_cast<v2f*>(buf0)[t * K::FS + k.upos[ph][cc]] = acc[t] * k.conj_mul;
+          for (int t = 0; t < C; ++t)
+            reinterpret_cast<v2f*>(buf0)[t * K::FS + k.upos[ph][cc]] = acc[t] * k.conj_mul;
+        }
       }
     team_sync<WAVE_LOCAL>();
     pass<0>(p, buf0, buf1, tid, f0, k.tw);
@@ -492,7 +531,9 @@ struct FastKernel {
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) {
         x[i][cc] = cvt(t[cc]);
-        if constexpr (INTERIOR) halo_mine[i * D + c0 + cc] = t[cc];
+        if constexpr (INTERIOR) {
+          if (!(K::LANES < NT) || tid < K::LANES) halo_mine[i * D + c0 + cc] = t[cc];
+        }
       }
     }
 #pragma unroll
@@ -506,7 +547,8 @@ struct FastKernel {
         const int r = ci * C + t;
         if (r >= TAIL0 && tail_from_lds) {
 #pragma unroll
-          for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(halo_next[(r - TAIL0) * D + c0 + cc]);
+          for (int cc = 0; cc < CPT; ++cc)
+            x[W - 1 + t][cc] = cvt(halo_next[(r - TAIL0) * D + ((K::LANES < NT && c0 >= D) ? 0 : c0 + cc)]);
         } else {
 #pragma unroll
           for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);

@@ -109,6 +109,7 @@ PLANS = {
     "m128": (128, [16, 8], [8, 17], 136, 8, 64),     # final-pass reads 2-way
     "m256": (256, [16, 16], [16, 17], 272, 4, 64),
     "m1024": (1024, [16, 16, 4], [64, 68, 260], 1088, 8, 512),
+    "m56": (56, [8, 7], [7, 9], 71, 8, 64),           # the reference's fs*1e-6; 2-way on ~half the accesses
 }
 
 if __name__ == "__main__":
