@@ -232,31 +232,37 @@ def test_device_tensor_path_matches_host_path():
         assert np.array_equal(y.cpu().numpy(), host)
 
 
-def test_large_stream_interior_windows(oracle):
-    """Full-size behaviour through size-independent checks: run a 2^28-sample synthetic stream
-    (generated in HBM), then compare random interior frame windows with the oracle evaluated on
-    just the samples those frames depend on."""
+@pytest.mark.parametrize("M,P,D,fmt,bw,log2n", [(64, 12, 64, "int16", 12, 30), (256, 8, 256, "int8", 8, 30),
+                                                (1024, 16, 1024, "int16", 16, 28), (128, 12, 64, "int16", 12, 28),
+                                                (56, 12, 56, "int16", 12, 26)])
+def test_large_stream_interior_windows(oracle, M, P, D, fmt, bw, log2n):
+    """BASELINE.json's full sizes through size-independent checks: run the whole synthetic stream
+    (generated in HBM), then compare random interior frame windows -- plus the first and last frames and
+    windows on pulses -- with the oracle evaluated on just the samples those frames depend on."""
     import torch
-    M, P, D = 64, 12, 64
-    n = 1 << 28
+    n = 1 << log2n
     h = oracle.design_prototype(M, P).astype(np.float32)
-    iq = synth.pulsed_iq_torch(n, 12, device="cuda")
-    with Channelizer(M, taps=h, bit_width=12) as ch:
+    iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device="cuda")
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw) as ch:
         y = ch(iq)
         assert ch.last_kernel.startswith("pfb_fast")
     F = n // D
     assert tuple(y.shape) == (F, M)
+    W = M * P // D  # rows a frame depends on
+    nwin = 16
     rng = np.random.default_rng(0)
     pulse_frames = (np.arange(0, n, 56000) // D)[1:]
-    starts = list(rng.integers(P, F - 64, size=6)) + [0, F - 64] + list(pulse_frames[rng.integers(0, len(pulse_frames), 4)])
+    starts = list(rng.integers(W, F - nwin, size=6)) + [0, F - nwin] + list(pulse_frames[rng.integers(0, len(pulse_frames), 4)])
     for f0 in starts:
-        f0 = int(f0)
-        lo = max(0, (f0 - (P - 1)) * D)
-        seg = iq[lo:(f0 + 64) * D].cpu().numpy()
-        want = oracle_run(oracle, seg, h, M, P, D, 12)[-64:]
-        got = y[f0:f0 + 64].cpu().numpy()
+        f0 = int(min(f0, F - nwin))
+        lo = max(0, (f0 - W) * D)
+        seg = iq[lo:(f0 + nwin) * D].cpu().numpy()
+        want = oracle_run(oracle, seg, h, M, P, D, bw)[-nwin:]
+        got = y[f0:f0 + nwin].cpu().numpy()
         assert np.abs(got - want).max() / max(np.abs(want).max(), 0.05) < REL_TOL, f0
     assert bool(torch.isfinite(torch.view_as_real(y)).all())
+    del y, iq
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("opts", [{L.PFB_OPT_SCHEDULE: 0}, {L.PFB_OPT_SCHEDULE: 0, L.PFB_OPT_FRAMES_PER_BLOCK: 40},
@@ -307,3 +313,36 @@ def test_fused_magnitude_output(oracle, M, P, D, fmt, bw, kw):
         m = m.T
     assert m.dtype == np.float32 and m.shape == want.shape
     assert np.abs(m - want).max() / want.max() < REL_TOL
+
+
+def test_misaligned_device_buffer_and_cf32(oracle):
+    """A device pointer that is only sample-aligned takes the checked load path; cf32 input has its own kernel."""
+    import torch
+    M, P = 256, 8
+    n = M * 400
+    iq = synth.pulsed_iq_numpy(n + 3, 8, np.int8, seed=23)
+    h = oracle.design_prototype(M, P).astype(np.float32)
+    d = torch.from_numpy(iq).cuda()
+    with Channelizer(M, taps=h, sample_format="int8", bit_width=8) as ch:
+        y = ch(d[3:])                      # byte offset 6: not 8-byte aligned for the 4-column vector loads
+        assert ch.last_kernel.startswith("pfb_fast<M256")
+    want = oracle_run(oracle, iq[3:], h, M, P, M, 8)
+    assert rel(y.cpu().numpy(), want) < REL_TOL
+    x = (np.random.default_rng(5).standard_normal((64 * 500, 2)) * 0.3).astype(np.float32)
+    h64 = oracle.design_prototype(64, 12).astype(np.float32)
+    with Channelizer(64, taps=h64, sample_format="cf32") as ch:
+        y = ch(x)
+        assert ch.last_kernel == "pfb_fast<M64,P12,D64,cf32>"
+    assert rel(y, oracle_run(oracle, x, h64, 64, 12, 64, 0, "cf32")) < REL_TOL
+
+
+def test_largest_supported_shapes(oracle):
+    """limits of pfb_create: M up to 4096, P up to 64 (generic kernel)"""
+    for M, P, D in ((4096, 2, 4096), (16, 64, 16)):
+        iq = synth.pulsed_iq_numpy(D * 40, 12, np.int16, seed=M)
+        h = np.random.default_rng(M).standard_normal(M * P).astype(np.float32) / M
+        with Channelizer(M, taps=h, decimation=D, bit_width=12) as ch:
+            y = ch(iq)
+        assert rel(y, oracle_run(oracle, iq, h, M, P, D, 12)) < REL_TOL
+    with pytest.raises(Exception):
+        Channelizer(8192, taps=np.zeros(8192 * 2, np.float32))
