@@ -173,13 +173,14 @@ typedef enum pfb_option {
   PFB_OPT_HOST_CHUNK_SAMPLES = 2, /* staging chunk for PFB_MEM_HOST (0 = default)              */
   PFB_OPT_NONTEMPORAL = 3,      /* 1 = nontemporal output stores                               */
   PFB_OPT_PROFILE = 4,          /* 1 = bracket every channelizer kernel launch with HIP events  */
-  PFB_OPT_XCD_REMAP = 5,        /* 1 (default) = consecutive runs of frames stay on one XCD,     */
+  PFB_OPT_XCD_REMAP = 5,        /* -1 (default) = per schedule, 1 = consecutive runs stay on one XCD, */
                                 /* G > 1 = in groups of G workgroups (schedule 3), 0 = off       */
   PFB_OPT_SCHEDULE = 6,         /* fast kernels: -1 (default) = best measured for the kernel,    */
                                 /* 0 = one sliding-window run per workgroup,                     */
                                 /* 1 = persistent waves over strided chunks, 2 = one chunk per   */
                                 /* wave with adjacent chunks grouped into workgroups, 3 = short  */
-                                /* sliding runs whose halo rows are shared through LDS           */
+                                /* sliding runs whose halo rows are shared through LDS, 4 = 3    */
+                                /* with the FIR and the FFT on different waves (M = 64 kernels)  */
   PFB_OPT_GRID = 7,             /* schedule 1: workgroups to launch (0 = all that are resident)  */
   PFB_OPT_TILE_WAVES = 8,       /* schedules 2/3: waves per workgroup                           */
   PFB_OPT_EXPERIMENT = 9        /* bit mask of timing experiments; 0 in production               */

@@ -80,7 +80,7 @@ struct pfb_handle {
   int opt_frames_per_block = 0;
   int64_t opt_host_chunk = 0;
   int opt_nontemporal = 0;
-  int opt_xcd_remap = 1;
+  int opt_xcd_remap = -1;  // -1: per schedule (on for 0..3, off for the wave-pair schedule)
   int opt_experiment = 0;
   int opt_schedule = -1;  // -1: the instantiation's measured default
   int opt_grid = 0;
@@ -139,7 +139,7 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
     p.layout = h->layout;
     p.flags = h->flags;
     p.nontemporal = h->opt_nontemporal;
-    p.xcd_remap = h->opt_xcd_remap;
+    p.xcd_remap = h->opt_xcd_remap < 0 ? 1 : h->opt_xcd_remap;
     p.experiment = h->opt_experiment;
     p.grid_override = h->opt_grid;
     p.tile_waves = h->opt_tile_waves;
@@ -162,6 +162,10 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
       fpb = ((fpb + c - 1) / c) * c;
       p.schedule = h->opt_schedule >= 0 ? h->opt_schedule : h->fast->default_schedule;
       if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
+      if (p.schedule == 4) {
+        if (h->opt_frames_per_block <= 0) fpb = 64;
+        if (h->opt_xcd_remap < 0) p.xcd_remap = 0;  // 512-frame workgroups: one dense sweep beats L2 halo hits
+      }
       p.frames_per_block = fpb;
       const int cpt = h->fast->cols_per_thread;
       const int bmod = ((p.base % cpt) + cpt) % cpt;
@@ -534,7 +538,7 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_nontemporal = value ? 1 : 0;
       return PFB_OK;
     case PFB_OPT_SCHEDULE:
-      if (value < -1 || value > 3) return PFB_ERR_BAD_ARG;
+      if (value < -1 || value > 4) return PFB_ERR_BAD_ARG;
       h->opt_schedule = (int)value;
       return PFB_OK;
     case PFB_OPT_TILE_WAVES:
@@ -546,7 +550,7 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_grid = (int)value;
       return PFB_OK;
     case PFB_OPT_XCD_REMAP:
-      if (value < 0 || value > (1 << 20)) return PFB_ERR_BAD_ARG;
+      if (value < -1 || value > (1 << 20)) return PFB_ERR_BAD_ARG;
       h->opt_xcd_remap = (int)value;
       return PFB_OK;
     case PFB_OPT_EXPERIMENT:

@@ -448,6 +448,39 @@ struct FastKernel {
     team_sync<WAVE_LOCAL>();  // the next chunk's FIR overwrites buf0
   }
 
+  // the two halves of fir_fft_store as separate steps (schedule F gives them to different waves)
+  PFB_DEV void fir_to_lds(const Consts& k, const v2f (&x)[NW][CPT], float2* buf, int tid) {
+#pragma unroll
+    for (int ph = 0; ph < OS; ++ph)
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) {
+        v2f acc[C];
+#pragma unroll
+        for (int t = 0; t < C; ++t) acc[t] = (v2f){0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          const int j = ph + OS * q;
+#pragma unroll
+          for (int t = 0; t < C; ++t) {
+            if (j & 1) fma_tap_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+            else fma_tap_lo(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+          }
+        }
+        if (!(K::LANES < NT) || tid < K::LANES) {
+#pragma unroll
+          for (int t = 0; t < C; ++t)
+            reinterpret_cast<v2f*>(buf)[t * K::FS + k.upos[ph][cc]] = acc[t] * k.conj_mul;
+        }
+      }
+  }
+
+  PFB_DEV void fft_from_lds(const KernelParams& p, const Consts& k, float2* buf, int tid, long long f0) {
+    static_assert(K::NP == 2 && !K::PINGPONG, "two in-place passes");
+    pass<0>(p, buf, buf, tid, f0, k.tw);
+    team_sync<true>();
+    pass<1>(p, buf, nullptr, tid, f0, k.tw);
+  }
+
   // ---- schedule A: sliding window over a long contiguous run per workgroup ---------------------
   template <bool INTERIOR>
   PFB_DEV void run_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end) {
@@ -600,6 +633,103 @@ struct FastKernel {
     else shared_impl<false, NWV, L>(p, k, lds, halo_mine, halo_next, wave, f_begin);
   }
 
+  // ---- schedule F: schedule D with the FIR and the FFT on different waves ---------------------------
+  // With one wave doing both halves the kernel needs ~114 VGPRs (4 waves per SIMD), and at 4 waves per
+  // SIMD it sits on a latency floor (fusing abs() halves the written bytes and barely changes the time).
+  // Here wave w < NPAIR slides the window and writes branch outputs for run w into one of two LDS
+  // buffers while wave w + NPAIR transforms and stores the chunk before it: each role needs far fewer
+  // registers, so more waves fit per SIMD.  One workgroup barrier per chunk hands the buffers over.
+  template <bool INTERIOR, int NPAIR, int L>
+  PFB_DEV void paired_fir_role(const KernelParams& p, float2* bufs, raw_t* halo_mine, const raw_t* halo_next,
+                               int pair, long long f_begin) {
+    constexpr int TAIL0 = L - (W - 1), NCH = L / C;
+    const int tid = threadIdx.x & 63;
+    const int c0 = tid * CPT;
+    Consts k;
+    setup(p, tid, k);
+    const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
+    const bool lane_on = !(K::LANES < NT) || tid < K::LANES;
+    v2f x[NW][CPT];
+    raw_t raw[C][CPT];
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) {
+      raw_t t[CPT];
+      load_row<INTERIOR>(p, run_ptr, f_begin - (W - 1) + i, i, c0, t);
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) {
+        x[i][cc] = cvt(t[cc]);
+        if constexpr (INTERIOR) { if (lane_on) halo_mine[i * D + c0 + cc] = t[cc]; }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + t, W - 1 + t, c0, raw[t]);
+    __syncthreads();  // A: halo slots published
+    const bool tail_from_lds = INTERIOR && (pair < NPAIR - 1);
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+#pragma unroll
+      for (int t = 0; t < C; ++t) {
+        const int r = ci * C + t;
+        if (r >= TAIL0 && tail_from_lds) {
+#pragma unroll
+          for (int cc = 0; cc < CPT; ++cc)
+            x[W - 1 + t][cc] = cvt(halo_next[(r - TAIL0) * D + (lane_on ? c0 + cc : 0)]);
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);
+        }
+      }
+      if (ci + 1 < NCH) {
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+          const int r = (ci + 1) * C + t;
+          if (!(r >= TAIL0 && tail_from_lds)) load_row<INTERIOR>(p, run_ptr, f_begin + r, W - 1 + r, c0, raw[t]);
+        }
+      }
+      fir_to_lds(k, x, bufs + (ci & 1) * K::BUF, tid);
+#pragma unroll
+      for (int i = 0; i < W - 1; ++i)
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
+      __syncthreads();  // chunk ci handed to the FFT wave
+    }
+    __syncthreads();    // the FFT wave's last step
+  }
+
+  template <int NPAIR, int L>
+  PFB_DEV void run_paired(const KernelParams& p, float2* lds_fft, raw_t* lds_halo) {
+    static_assert(NT == 64, "one wave per run and role");
+    static_assert(L % C == 0 && L >= W - 1, "runs are whole chunks and at least one halo long");
+    constexpr int NCH = L / C;
+    const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    const bool fir_role = wave < NPAIR;
+    const int pair = fir_role ? wave : wave - NPAIR;
+    long long blk = blockIdx.x;
+    if (p.xcd_remap) {
+      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = blk & 7;
+      blk = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (blk >> 3);
+    }
+    const long long f_blk = blk * (long long)(NPAIR * L);
+    const long long f_begin = f_blk + (long long)pair * L;
+    float2* bufs = lds_fft + pair * 2 * K::BUF;
+    const bool interior = p.vec_ok && ((f_blk - (W - 1)) * D + p.base >= 0) && (f_blk + NPAIR * L <= p.frames);
+    if (fir_role) {
+      raw_t* halo_mine = lds_halo + pair * ((W - 1) * D);
+      const raw_t* halo_next = lds_halo + (pair + 1) * ((W - 1) * D);
+      if (interior) paired_fir_role<true, NPAIR, L>(p, bufs, halo_mine, halo_next, pair, f_begin);
+      else paired_fir_role<false, NPAIR, L>(p, bufs, halo_mine, halo_next, pair, f_begin);
+    } else {
+      Consts k;
+      setup(p, tid, k);
+      __syncthreads();  // A
+#pragma unroll
+      for (int s = 0; s <= NCH; ++s) {
+        if (s >= 1) fft_from_lds(p, k, bufs + ((s - 1) & 1) * K::BUF, tid, f_begin + (long long)(s - 1) * C);
+        __syncthreads();
+      }
+    }
+  }
+
   // ---- schedule B: persistent waves, strided chunks ---------------------------------------------
   // The grid is sized to what is resident at once; workgroup b handles chunks b', b'+G, b'+2G, ...
   // (b' = XCD-aware slot), so at any moment the whole chip works on ~G consecutive chunks: a compact
@@ -738,6 +868,22 @@ __global__ void __launch_bounds__(64 * NWV) pfb_shared_kernel(const KernelParams
   FastKernel<K>::template run_shared<NWV, L>(p, lds_fft, lds_halo);
 }
 
+template <class K, int NPAIR, int L, int MINW>
+__global__ void __launch_bounds__(128 * NPAIR, MINW) pfb_paired_kernel(const KernelParams p) {
+  using raw_t = typename SampleT<K::FMT>::raw_t;
+  __shared__ float2 lds_fft[NPAIR * 2 * K::BUF];
+  __shared__ raw_t lds_halo[(NPAIR + 1) * (K::W - 1) * K::D];
+  FastKernel<K>::template run_paired<NPAIR, L>(p, lds_fft, lds_halo);
+}
+
+template <class K, int NPAIR, int L, int MINW>
+hipError_t launch_paired(const KernelParams& p, hipStream_t s) {
+  const long long per = (long long)NPAIR * L;
+  const long long blocks = (p.frames + per - 1) / per;
+  hipLaunchKernelGGL((pfb_paired_kernel<K, NPAIR, L, MINW>), dim3((unsigned)blocks), dim3(128 * NPAIR), 0, s, p);
+  return hipGetLastError();
+}
+
 template <class K, int NWV, int L>
 hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s);
 
@@ -765,6 +911,27 @@ hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s) {
 template <class K>
 hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   if (p.frames <= 0) return hipSuccess;
+  if constexpr (K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::D == K::M && K::M == 64) {
+    if (p.schedule == 4) {  // FIR / FFT wave pairs: tile_waves = pairs per workgroup, frames_per_block = run length
+      const int key = p.tile_waves * 1000 + p.frames_per_block;
+      if constexpr (K::FMT == PFB_FMT_INT16_IQ) {  // tuning sweep set (cfg2 only, keeps build time sane)
+        switch (key) {
+          case 4032: return launch_paired<K, 4, 32, 6>(p, s);
+          case 4064: return launch_paired<K, 4, 64, 6>(p, s);
+          case 5032: return launch_paired<K, 5, 32, 5>(p, s);   // 10-wave workgroups, 5 waves per SIMD
+          case 5064: return launch_paired<K, 5, 64, 5>(p, s);
+          case 5128: return launch_paired<K, 5, 128, 5>(p, s);
+          case 7064: return launch_paired<K, 7, 64, 4>(p, s);
+          case 8032: return launch_paired<K, 8, 32, 4>(p, s);
+          case 8048: return launch_paired<K, 8, 48, 4>(p, s);
+          case 8096: return launch_paired<K, 8, 96, 4>(p, s);
+          case 8128: return launch_paired<K, 8, 128, 4>(p, s);
+          default: break;
+        }
+      }
+      return launch_paired<K, 8, 64, 4>(p, s);  // the tuned shape: 16 waves, 512 frames per workgroup
+    }
+  }
   if constexpr (K::NT == 64) {
     if (p.schedule == 3) {  // shared-halo sliding windows: tile_waves runs of frames_per_block frames
       const int key = p.tile_waves * 1000 + p.frames_per_block;

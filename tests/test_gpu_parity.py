@@ -346,3 +346,21 @@ def test_largest_supported_shapes(oracle):
         assert rel(y, oracle_run(oracle, iq, h, M, P, D, 12)) < REL_TOL
     with pytest.raises(Exception):
         Channelizer(8192, taps=np.zeros(8192 * 2, np.float32))
+
+
+@pytest.mark.parametrize("tw,fpb", [(4, 32), (5, 32), (5, 24), (8, 48), (4, 64)])
+def test_paired_schedule_gives_identical_bits(oracle, tw, fpb):
+    """schedule 4: FIR and FFT on different waves of a workgroup, LDS double buffer in between"""
+    M, P = 64, 12
+    n = M * 7001 + 3
+    iq = synth.pulsed_iq_numpy(n, 12, np.int16, seed=29)
+    h = oracle.design_prototype(M, P).astype(np.float32)
+    with Channelizer(M, taps=h, bit_width=12) as ch:
+        ch.set_option(L.PFB_OPT_SCHEDULE, 0)
+        ref = ch(iq)
+        ch.reset()
+        ch.set_option(L.PFB_OPT_SCHEDULE, 4)
+        ch.set_option(L.PFB_OPT_TILE_WAVES, tw)
+        ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, fpb)
+        got = np.concatenate([ch(iq[:M * 2000 + 7]), ch(iq[M * 2000 + 7:])])
+    assert np.array_equal(got, ref)

@@ -20,7 +20,7 @@ from sdr_channelizer_amd import _lib as L  # noqa: E402
 
 OPT = {"kernel": L.PFB_OPT_KERNEL, "fpb": L.PFB_OPT_FRAMES_PER_BLOCK, "nt": L.PFB_OPT_NONTEMPORAL,
        "remap": L.PFB_OPT_XCD_REMAP, "sched": L.PFB_OPT_SCHEDULE, "grid": L.PFB_OPT_GRID, "tw": L.PFB_OPT_TILE_WAVES, "exp": L.PFB_OPT_EXPERIMENT}
-DEFAULTS = {"kernel": 2, "fpb": 0, "nt": 0, "remap": 1, "sched": -1, "grid": 0, "tw": 8, "exp": 0}
+DEFAULTS = {"kernel": 2, "fpb": 0, "nt": 0, "remap": -1, "sched": -1, "grid": 0, "tw": 8, "exp": 0}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2-samples", type=int, default=30)
@@ -28,6 +28,8 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--workload", default="64,12,64,int16,12")
 ap.add_argument("--magnitude", action="store_true")
+ap.add_argument("--out-offset-kib", type=int, default=0, help="shift the output buffer start by this many KiB")
+ap.add_argument("--exact-out", action="store_true", help="allocate exactly frames*M outputs like bench.py")
 ap.add_argument("cases", nargs="+")
 a = ap.parse_args()
 
@@ -36,7 +38,14 @@ M, P, D, bw = int(M), int(P), int(D), int(bw)
 n = 1 << a.log2_samples
 dev = torch.device("cuda", 0)
 iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device=dev)
-out = torch.empty((n // D + 1, M), dtype=torch.float32 if a.magnitude else torch.complex64, device=dev)
+odt = torch.float32 if a.magnitude else torch.complex64
+if a.exact_out:
+    out = torch.empty((n // D, M), dtype=odt, device=dev)
+else:
+    pad_rows = (a.out_offset_kib * 1024) // (M * (4 if a.magnitude else 8)) + 1
+    big = torch.empty((n // D + 1 + pad_rows, M), dtype=odt, device=dev)
+    out = big[pad_rows - 1:]
+print(f"# in ptr {iq.data_ptr():#x} out ptr {out.data_ptr():#x} delta {(out.data_ptr() - iq.data_ptr()) / 2**20:.3f} MiB")
 ch = Channelizer(M, taps=design_prototype(M, P), decimation=D, sample_format=fmt, bit_width=bw, magnitude=a.magnitude)
 ch.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 cases = []
