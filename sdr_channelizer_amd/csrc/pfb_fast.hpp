@@ -909,27 +909,51 @@ hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s) {
 }
 
 template <class K>
+hipError_t launch_strided(const KernelParams& p, hipStream_t s) {  // persistent strided chunks
+  static int resident = 0;  // workgroups resident at once on this device class
+  if (resident == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pfb_strided_kernel<K>, K::NT, 0);
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    resident = per_cu * prop.multiProcessorCount;
+    if (resident < 8) resident = 8;
+  }
+  const long long nchunks = (p.frames + K::C - 1) / K::C;
+  long long grid = p.grid_override > 0 ? p.grid_override : resident;
+  if (grid > nchunks) grid = nchunks;
+  if (grid >= 8) grid -= grid % 8;
+  hipLaunchKernelGGL(pfb_strided_kernel<K>, dim3((unsigned)grid), dim3(K::NT), 0, s, p);
+  return hipGetLastError();
+}
+
+template <class K>
 hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   if (p.frames <= 0) return hipSuccess;
-  if constexpr (K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::D == K::M && K::M == 64) {
+  // (measured on cfg3, cfg5 and M=56 too: slower than their sliding runs, so only the M=64 kernels carry it)
+  if constexpr (K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::M == 64) {
     if (p.schedule == 4) {  // FIR / FFT wave pairs: tile_waves = pairs per workgroup, frames_per_block = run length
       const int key = p.tile_waves * 1000 + p.frames_per_block;
-      if constexpr (K::FMT == PFB_FMT_INT16_IQ) {  // tuning sweep set (cfg2 only, keeps build time sane)
+      if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64) {  // tuning sweep set (cfg2 only, keeps build time sane)
         switch (key) {
-          case 4032: return launch_paired<K, 4, 32, 6>(p, s);
           case 4064: return launch_paired<K, 4, 64, 6>(p, s);
-          case 5032: return launch_paired<K, 5, 32, 5>(p, s);   // 10-wave workgroups, 5 waves per SIMD
-          case 5064: return launch_paired<K, 5, 64, 5>(p, s);
-          case 5128: return launch_paired<K, 5, 128, 5>(p, s);
-          case 7064: return launch_paired<K, 7, 64, 4>(p, s);
-          case 8032: return launch_paired<K, 8, 32, 4>(p, s);
+          case 5064: return launch_paired<K, 5, 64, 5>(p, s);   // 10-wave workgroups, 5 waves per SIMD
           case 8048: return launch_paired<K, 8, 48, 4>(p, s);
-          case 8096: return launch_paired<K, 8, 96, 4>(p, s);
           case 8128: return launch_paired<K, 8, 128, 4>(p, s);
           default: break;
         }
       }
-      return launch_paired<K, 8, 64, 4>(p, s);  // the tuned shape: 16 waves, 512 frames per workgroup
+      // the tuned shape is 8 pairs x 64 frames (16 waves, 512 frames per workgroup); instantiations whose
+      // LDS image does not fit 8 pairs take 4
+      constexpr size_t kPair = sizeof(float2) * 2 * K::BUF, kSlot = sizeof(typename SampleT<K::FMT>::raw_t) * (K::W - 1) * K::D;
+      if constexpr (8 * kPair + 9 * kSlot <= 160 * 1024) {
+        if (p.tile_waves == 4) return launch_paired<K, 4, 64, 2>(p, s);
+        return launch_paired<K, 8, 64, 4>(p, s);
+      } else {
+        return launch_paired<K, 4, 64, 2>(p, s);
+      }
     }
   }
   if constexpr (K::NT == 64) {
@@ -940,54 +964,20 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64) {  // tuning sweep set (cfg2 only, keeps build time sane)
         switch (key) {
           case 4032: return launch_shared<K, 4, 32>(p, s);
-          case 4024: return launch_shared<K, 4, 24>(p, s);
-          case 6024: return launch_shared<K, 6, 24>(p, s);
-          case 8016: return launch_shared<K, 8, 16>(p, s);
-          case 8040: return launch_shared<K, 8, 40>(p, s);
           case 8048: return launch_shared<K, 8, 48>(p, s);
-          case 8064: return launch_shared<K, 8, 64>(p, s);
-          case 10024: return launch_shared<K, 10, 24>(p, s);
-          case 12016: return launch_shared<K, 12, 16>(p, s);
-          case 12024: return launch_shared<K, 12, 24>(p, s);
-          case 16016: return launch_shared<K, 16, 16>(p, s);
           case 16024: return launch_shared<K, 16, 24>(p, s);
-          case 16032: return launch_shared<K, 16, 32>(p, s);
           default: break;
         }
       }
       return launch_shared<K, 8, 24>(p, s);  // any other shape: the tuned default
     }
   }
-  if constexpr (K::NT == 64) {
+  if constexpr (K::NT == 64 && K::M == 64 && K::FMT == PFB_FMT_INT16_IQ) {  // access-shape study schedules (cfg2 only)
     if (p.schedule == 2) {  // one chunk per wave, tile_waves adjacent chunks per workgroup
-      switch (p.tile_waves) {
-        case 1: return launch_tile<K, 1>(p, s);
-        case 2: return launch_tile<K, 2>(p, s);
-        case 4: return launch_tile<K, 4>(p, s);
-        case 8: return launch_tile<K, 8>(p, s);
-        case 16: return launch_tile<K, 16>(p, s);
-        default: return hipErrorInvalidValue;
-      }
+      if (p.tile_waves == 1) return launch_tile<K, 1>(p, s);
+      return launch_tile<K, 8>(p, s);
     }
-  }
-  if (K::NT == 64 && p.schedule == 1) {  // persistent strided chunks
-    static int resident = 0;  // workgroups resident at once on this device class
-    if (resident == 0) {
-      int per_cu = 0, dev = 0;
-      hipDeviceProp_t prop;
-      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pfb_strided_kernel<K>, K::NT, 0);
-      if (e == hipSuccess) e = hipGetDevice(&dev);
-      if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-      if (e != hipSuccess) return e;
-      resident = per_cu * prop.multiProcessorCount;
-      if (resident < 8) resident = 8;
-    }
-    const long long nchunks = (p.frames + K::C - 1) / K::C;
-    long long grid = p.grid_override > 0 ? p.grid_override : resident;
-    if (grid > nchunks) grid = nchunks;
-    if (grid >= 8) grid -= grid % 8;
-    hipLaunchKernelGGL(pfb_strided_kernel<K>, dim3((unsigned)grid), dim3(K::NT), 0, s, p);
-    return hipGetLastError();
+    if (p.schedule == 1) return launch_strided<K>(p, s);
   }
   const long long blocks = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
   hipLaunchKernelGGL(pfb_fast_kernel<K>, dim3((unsigned)blocks), dim3(K::NT), 0, s, p);

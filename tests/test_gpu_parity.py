@@ -269,12 +269,11 @@ def test_large_stream_interior_windows(oracle, M, P, D, fmt, bw, log2n):
                                   {L.PFB_OPT_SCHEDULE: 1}, {L.PFB_OPT_SCHEDULE: 1, L.PFB_OPT_GRID: 24},
                                   {L.PFB_OPT_SCHEDULE: 1, L.PFB_OPT_XCD_REMAP: 0},
                                   {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 1},
-                                  {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 4},
-                                  {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 16, L.PFB_OPT_XCD_REMAP: 0},
+                                  {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_XCD_REMAP: 0},
                                   {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_NONTEMPORAL: 1},
                                   {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_FRAMES_PER_BLOCK: 32},
-                                  {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 4, L.PFB_OPT_FRAMES_PER_BLOCK: 64},
-                                  {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 16, L.PFB_OPT_FRAMES_PER_BLOCK: 16,
+                                  {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 4, L.PFB_OPT_FRAMES_PER_BLOCK: 32},
+                                  {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 16, L.PFB_OPT_FRAMES_PER_BLOCK: 24,
                                    L.PFB_OPT_XCD_REMAP: 0},
                                   {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_FRAMES_PER_BLOCK: 24}])
 def test_every_schedule_gives_identical_bits(oracle, opts):
@@ -348,7 +347,7 @@ def test_largest_supported_shapes(oracle):
         Channelizer(8192, taps=np.zeros(8192 * 2, np.float32))
 
 
-@pytest.mark.parametrize("tw,fpb", [(4, 32), (5, 32), (5, 24), (8, 48), (4, 64)])
+@pytest.mark.parametrize("tw,fpb", [(8, 64), (4, 64), (5, 64), (8, 48), (8, 128)])
 def test_paired_schedule_gives_identical_bits(oracle, tw, fpb):
     """schedule 4: FIR and FFT on different waves of a workgroup, LDS double buffer in between"""
     M, P = 64, 12
