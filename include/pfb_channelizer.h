@@ -134,6 +134,17 @@ int pfb_sync(pfb_handle* h);
 /* Frames a call with num_samples would produce right now. */
 int pfb_frames_for(const pfb_handle* h, uint64_t num_samples, uint64_t* frames_out);
 
+/* Channelize one .iq record straight from disk: parse the header (pfb_iq_parse_header, all three
+ * formats), check that the payload matches it (the reference asserts length(iq)==numSamples,
+ * matlab/convert_my_iq_to_mat.m:102) and that the handle was created for its sample format and
+ * bit width, then stream the payload through the GPU in chunks without holding the file in
+ * memory.  Replaces convert_my_iq_to_mat.m:40-118 + the load/normalise lines of the channelizer
+ * scripts for the common case.  `out` is host memory, frame-major layout only.  The handle's state
+ * carries over exactly as with pfb_process (call pfb_reset first for a fresh channelizer per file,
+ * create_pdws_channelized.m:33). */
+int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t out_capacity_frames,
+                        uint64_t* frames_out, pfb_iq_info* info_out);
+
 /* ---- state (checkpoint/resume, and the multi-GPU halo) --------------------- */
 /* History is the raw input samples (cfg.sample_format) that precede the next
  * call: pfb_history_samples() of them.  A time shard on GPU g>0 is primed with

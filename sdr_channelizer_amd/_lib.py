@@ -65,7 +65,7 @@ class PfbIqInfo(C.Structure):
 
 # every symbol include/pfb_channelizer.h + include/pfb_iq_packet.h declare
 EXPORTS = (
-    "pfb_create", "pfb_destroy", "pfb_reset", "pfb_set_stream", "pfb_process", "pfb_process_async", "pfb_sync",
+    "pfb_create", "pfb_destroy", "pfb_reset", "pfb_set_stream", "pfb_process", "pfb_process_async", "pfb_sync", "pfb_process_iq_file",
     "pfb_frames_for", "pfb_history_samples", "pfb_prime", "pfb_get_state", "pfb_set_state", "pfb_set_frame_index",
     "pfb_get_frame_index", "pfb_center_frequencies", "pfb_design_prototype", "pfb_strerror",
     "pfb_last_error_detail", "pfb_abi_version", "pfb_device_count", "pfb_set_option", "pfb_last_kernel",
@@ -110,6 +110,7 @@ def load() -> C.CDLL:
     lib.pfb_process.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64), u32]
     lib.pfb_process_async.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
     lib.pfb_sync.argtypes = [vp]
+    lib.pfb_process_iq_file.argtypes = [vp, C.c_char_p, vp, u64, C.POINTER(u64), C.POINTER(PfbIqInfo)]
     lib.pfb_frames_for.argtypes = [vp, u64, C.POINTER(u64)]
     lib.pfb_history_samples.argtypes = [vp]
     lib.pfb_history_samples.restype = u64

@@ -204,5 +204,21 @@ class Channelizer:
         L.check(self._lib.pfb_get_kernel_times(self._h, buf, 4096, C.byref(n)), "pfb_get_kernel_times")
         return list(buf[: n.value])
 
+    def process_iq_file(self, path: str, reset: bool = True):
+        """Channelize one .iq record straight from disk (header parsed and checked by the library).
+        Returns (y, info): y is (frames, M) complex64 (or float32 with magnitude=True)."""
+        from . import iqfile
+        with open(path, "rb") as f:
+            info = iqfile.parse_header(f.read(128))
+        if reset:
+            self.reset()  # a fresh channelizer per file, create_pdws_channelized.m:33
+        F = self.frames_for(int(info.packet.numSamples))
+        res = np.empty((F, self.num_bands), dtype=np.float32 if self.magnitude else np.complex64)
+        f_out = C.c_uint64()
+        got = L.PfbIqInfo()
+        L.check(self._lib.pfb_process_iq_file(self._h, path.encode(), C.c_void_p(res.ctypes.data), F, C.byref(f_out),
+                                              C.byref(got)), "pfb_process_iq_file")
+        return res[: f_out.value], got
+
     def sync(self) -> None:
         L.check(self._lib.pfb_sync(self._h), "pfb_sync")

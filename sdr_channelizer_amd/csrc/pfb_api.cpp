@@ -446,6 +446,48 @@ int pfb_process(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t c
   return process_host(h, iq, n, out, f);
 }
 
+int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap, uint64_t* frames_out,
+                        pfb_iq_info* info_out) {
+  if (!h || !path) return PFB_ERR_BAD_ARG;
+  if (h->layout != PFB_LAYOUT_FRAME_MAJOR) return PFB_ERR_UNSUPPORTED;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { g_detail = std::string("cannot open ") + path; return PFB_ERR_BAD_ARG; }
+  unsigned char head[PFB_IQ_HEADER_BYTES];
+  const size_t got = std::fread(head, 1, sizeof(head), f);
+  pfb_iq_info info;
+  int rc = pfb_iq_parse_header(head, got, &info);
+  if (rc == PFB_OK && ((int)info.sample_format != h->fmt || (int)info.packet.bitWidth != h->bit_width))
+    rc = PFB_ERR_BAD_FORMAT;  // the handle's scale / unpack would not match this record
+  if (rc == PFB_OK) {
+    std::fseek(f, 0, SEEK_END);
+    const long long payload = (long long)std::ftell(f) - (long long)info.header_bytes;
+    if (payload != (long long)info.packet.numSamples * (long long)info.bytes_per_sample) rc = PFB_ERR_BAD_FORMAT;
+  }
+  if (info_out) *info_out = info;
+  if (rc != PFB_OK) { std::fclose(f); return rc; }
+  const uint64_t n = info.packet.numSamples;
+  const uint64_t need = frames_for(h, n);
+  if (frames_out) *frames_out = need;
+  if (need > cap) { std::fclose(f); return PFB_ERR_CAPACITY; }
+  if (need > 0 && !out) { std::fclose(f); return PFB_ERR_BAD_ARG; }
+  const uint64_t chunk = (((uint64_t)1 << 24) / h->D) * h->D;  // whole frames, 64 MB of int16 I/Q
+  std::vector<char> buf((size_t)std::min<uint64_t>(chunk, n ? n : 1) * h->bps);
+  std::fseek(f, (long)info.header_bytes, SEEK_SET);
+  uint64_t done = 0, frames_done = 0;
+  while (done < n && rc == PFB_OK) {
+    const uint64_t m = std::min<uint64_t>(chunk, n - done);
+    if (std::fread(buf.data(), (size_t)h->bps, (size_t)m, f) != (size_t)m) { rc = PFB_ERR_BAD_FORMAT; break; }
+    uint64_t fr = 0;
+    rc = pfb_process(h, buf.data(), m, static_cast<char*>(out) + frames_done * h->M * h->out_elem, cap - frames_done, &fr,
+                     PFB_MEM_HOST);
+    done += m;
+    frames_done += fr;
+  }
+  std::fclose(f);
+  if (frames_out) *frames_out = frames_done;
+  return rc;
+}
+
 uint64_t pfb_history_samples(const pfb_handle* h) { return h ? (uint64_t)h->hist_samples : 0; }
 
 int pfb_prime(pfb_handle* h, const void* iq, uint64_t n, uint32_t mem) {

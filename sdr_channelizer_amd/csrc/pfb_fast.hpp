@@ -938,7 +938,7 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       const int key = p.tile_waves * 1000 + p.frames_per_block;
       if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64) {  // tuning sweep set (cfg2 only, keeps build time sane)
         switch (key) {
-          case 4064: return launch_paired<K, 4, 64, 6>(p, s);
+          case 4064: return launch_paired<K, 4, 64, 4>(p, s);
           case 5064: return launch_paired<K, 5, 64, 5>(p, s);   // 10-wave workgroups, 5 waves per SIMD
           case 8048: return launch_paired<K, 8, 48, 4>(p, s);
           case 8128: return launch_paired<K, 8, 128, 4>(p, s);

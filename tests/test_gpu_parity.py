@@ -363,3 +363,28 @@ def test_paired_schedule_gives_identical_bits(oracle, tw, fpb):
         ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, fpb)
         got = np.concatenate([ch(iq[:M * 2000 + 7]), ch(iq[M * 2000 + 7:])])
     assert np.array_equal(got, ref)
+
+
+def test_iq_file_front_end(oracle, tmp_path):
+    """pfb_process_iq_file: record from disk -> channels, and its checks (format mismatch, truncated payload)."""
+    import os
+    from sdr_channelizer_amd import iqfile, PfbError
+    M, P = 64, 12
+    iq = synth.pulsed_iq_numpy(M * 3000 + 9, 12, np.int16, seed=41)
+    path = os.path.join(tmp_path, iqfile.filename_for(1_700_000_000_123))
+    iqfile.write_iq(path, iq, fs=56e6, fc=2.4e9, bit_width=12, marker=0x02020202)
+    h = oracle.design_prototype(M, P).astype(np.float32)
+    with Channelizer(M, taps=h, bit_width=12, fftshift=True) as ch:
+        y, info = ch.process_iq_file(path)
+        assert info.packet.numSamples == iq.shape[0] and info.file_format == 2
+        assert rel(y, oracle_run(oracle, iq, h, M, P, M, 12, fftshift=True)) < REL_TOL
+    with Channelizer(M, taps=h, bit_width=16) as ch16:      # record says 12-bit
+        with pytest.raises(PfbError) as e:
+            ch16.process_iq_file(path)
+        assert e.value.status == L.PFB_ERR_BAD_FORMAT
+    with open(path, "r+b") as f:                             # drop the last sample: length(iq) ~= numSamples
+        f.truncate(os.path.getsize(path) - 4)
+    with Channelizer(M, taps=h, bit_width=12) as ch:
+        with pytest.raises(PfbError) as e:
+            ch.process_iq_file(path)
+        assert e.value.status == L.PFB_ERR_BAD_FORMAT
