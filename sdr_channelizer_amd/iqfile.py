@@ -86,3 +86,16 @@ def filename_for(epoch_ms: int) -> str:
     buf = C.create_string_buffer(80)
     L.load().pfb_iq_filename(int(epoch_ms), buf, 80)
     return buf.value.decode()
+
+
+def write_iq_fmt1(path: str, iq: np.ndarray, fs: float, start_time: float = 0.0, board: str = "simulated") -> None:
+    """The 104-byte format-1 record matlab/generate_training_iq.m:107-127 writes by hand: marker 0x01010101,
+    link speed 1, 32-bit frequency 0, bandwidth = sample rate = fs, integer gain 0, numSamples, bitWidth 16,
+    64 bytes of strings ("simulated"), start time; then the int16 payload."""
+    iq = np.ascontiguousarray(iq, dtype=np.int16)
+    assert iq.ndim == 2 and iq.shape[1] == 2
+    words = np.array([0x01010101, 1, 0, int(fs), int(fs), 0, iq.shape[0], 16], dtype="<u4").tobytes()
+    name = board.encode()[:64]
+    with open(path, "wb") as f:
+        f.write(words + name + bytes(64 - len(name)) + np.array([start_time], dtype="<f8").tobytes())
+        f.write(iq.tobytes())

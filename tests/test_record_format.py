@@ -109,3 +109,32 @@ def test_our_writer_emits_the_reference_bytes(tmp_path):
     iqfile.write_iq(path, np.zeros((10, 2), np.int16), fs=20e6, fc=915e6, bit_width=16, gain_db=12.0,
                     start_time=99.0, board="usrp", serial="s1")
     assert open(path, "rb").read()[:112] == ref
+
+
+def test_fmt1_writer_matches_generate_training_iq_layout(tmp_path):
+    iq = np.arange(40, dtype=np.int16).reshape(-1, 2)
+    path = os.path.join(tmp_path, "sim.iq")
+    iqfile.write_iq_fmt1(path, iq, fs=56e6, start_time=1.6e9)
+    raw = open(path, "rb").read()
+    assert len(raw) == 104 + iq.nbytes
+    r = iqfile.read_iq(path)
+    assert (r.fileFormat, r.fs, r.bw, r.fc, r.bitWidth, r.boardName, r.sampleStartTime) == \
+        (1, 56e6, 56e6, 0.0, 16, "simulated", 1.6e9)
+    assert np.array_equal(r.iq, iq)
+
+
+def test_pulse_generator_switches():
+    """generate_pulsed_iq.m:17-19,43-59: LFM sweep and Barker-13 phase code."""
+    from sdr_channelizer_amd import synth
+    fs, pw = 56e6, 5600
+    k = np.arange(pw)
+    plain = synth.pulse_phase(k, 1e6, fs, pw)
+    assert np.allclose(np.diff(plain), 2 * np.pi * 1e6 / fs)                     # constant carrier
+    lfm = synth.pulse_phase(k, 1e6, fs, pw, lfm_extent_hz=2e6)
+    inst = np.diff(lfm) * fs / (2 * np.pi)                                       # instantaneous frequency
+    assert abs(inst[0] - 1e6) < 1e3 and abs(inst[-1] - 3e6) < 1e3 and np.all(np.diff(inst) > 0)
+    bk = synth.pulse_phase(k, 0.0, fs, 13 * 431, barker13=True)
+    chips = np.rad2deg(bk[::431][:13])
+    assert np.allclose(np.sign(chips), synth.BARKER_13) and np.allclose(np.abs(chips), 90.0, atol=1e-6)
+    a = synth.pulsed_iq_numpy(60000, 12, np.int16, lfm_extent_hz=5e6, barker13=True)
+    assert a.shape == (60000, 2) and np.abs(a).max() <= 2048
