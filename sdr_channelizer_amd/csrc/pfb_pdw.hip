@@ -34,7 +34,10 @@ constexpr int kCand = 2048;       // candidate capacity per channel for the exac
 constexpr int kPulseCache = 1024; // per-pulse values cached in LDS up to this many
 constexpr double kRadToDeg = 57.295779513082320876798154814105;
 
-__device__ __forceinline__ double mag_of(float2 v) { return hypot((double)v.x, (double)v.y); }
+// |y|^2 of a complex64 is EXACT in float64 (two 48-bit products, 49-bit sum), so selecting on it is
+// selecting on the true magnitude, and sqrt() of it is the correctly rounded magnitude.
+__device__ __forceinline__ double mag2_of(float2 v) { return fma((double)v.x, (double)v.x, (double)v.y * (double)v.y); }
+__device__ __forceinline__ double mag_of(float2 v) { return sqrt(mag2_of(v)); }
 __device__ __forceinline__ double phase_deg(float2 v) { return atan2((double)v.y, (double)v.x) * kRadToDeg; }
 
 // order-preserving 64-bit key of a finite double
@@ -66,7 +69,7 @@ __global__ void __launch_bounds__(256) pdw_hist_kernel(const float2* y, long lon
   const long long r1 = (r0 + rows_per_block < F) ? r0 + rows_per_block : F;
   if (valid) {
     for (long long r = r0 + wave; r < r1; r += 4) {
-      const unsigned long long k = dkey(mag_of(y[r * M + col]));
+      const unsigned long long k = dkey(mag2_of(y[r * M + col]));  // ordered like the magnitude, no sqrt
       const bool in_bucket = (pass == 0) || ((k >> (shift + 8)) == (pre >> (shift + 8)));
       if (in_bucket) atomicAdd(&h[(unsigned)(k >> shift) & 255u][lane], 1u);
     }
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(256) pdw_collect_kernel(const float2* y, long 
   const long long r1 = (r0 + rows_per_block < F) ? r0 + rows_per_block : F;
   unsigned long long best = 0ull;
   for (long long r = r0 + wave; r < r1; r += 4) {
-    const double m = mag_of(y[r * M + col]);
+    const double m = mag2_of(y[r * M + col]);
     const unsigned long long k = dkey(m);
     const unsigned long long hi = (low_bits >= 64) ? 0ull : (k >> low_bits), phi = (low_bits >= 64) ? 0ull : (pre >> low_bits);
     if (hi == phi) {
@@ -158,7 +161,8 @@ __global__ void __launch_bounds__(256) pdw_median_finish_kernel(long long F, int
     v0 = (r > 0) ? v[r - 1] : dkey_inv(max_below[col]);
   }
   (void)passes_done;
-  if (threadIdx.x == 0) nf[col] = (F & 1) ? v1 : 0.5 * (v0 + v1);  // MATLAB median: mean of the two middle values
+  // the candidates are squared magnitudes; MATLAB median: mean of the two middle values
+  if (threadIdx.x == 0) nf[col] = (F & 1) ? sqrt(v1) : 0.5 * (sqrt(v0) + sqrt(v1));
 }
 
 // ---------------------------------------------------------------------------------
@@ -188,15 +192,31 @@ __global__ void __launch_bounds__(256) pdw_tilefn_kernel(const float2* y, long l
   fn[tile * M + col] = (unsigned char)(s0 | (s1 << 1));
 }
 
-// per column: incoming state of every tile
-__global__ void pdw_tilescan_kernel(int M, long long ntiles, const unsigned char* fn, unsigned char* state_in) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= M) return;
-  int s = 0;
-  for (long long t = 0; t < ntiles; ++t) {
+// per column: incoming state of every tile.  One wave per column: each lane composes the transition
+// functions of a contiguous segment of tiles, the 64 segment functions are scanned across the wave,
+// then each lane replays its segment from its incoming state.
+__global__ void __launch_bounds__(64) pdw_tilescan_kernel(int M, long long ntiles, const unsigned char* fn,
+                                                          unsigned char* state_in) {
+  const int col = blockIdx.x, lane = threadIdx.x;
+  const long long per = (ntiles + 63) / 64;
+  const long long t0 = lane * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
+  int f = 0x2;  // identity: f(0)=0, f(1)=1  -> bits (f0 | f1<<1) = 0b10
+  for (long long t = t0; t < t1; ++t) {
+    const int g = fn[t * M + col];  // apply g after f: h(s) = g(f(s))
+    f = ((g >> (f & 1)) & 1) | (((g >> ((f >> 1) & 1)) & 1) << 1);
+  }
+  // inclusive scan of function composition across lanes (lane order = time order)
+  int inc = f;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int prev = __shfl_up(inc, d);
+    if (lane >= d) inc = ((inc >> (prev & 1)) & 1) | (((inc >> ((prev >> 1) & 1)) & 1) << 1);
+  }
+  int exc = __shfl_up(inc, 1);
+  if (lane == 0) exc = 0x2;
+  int s = exc & 1;  // state entering my segment when the stream starts inactive: exc(0)
+  for (long long t = t0; t < t1; ++t) {
     state_in[t * M + col] = (unsigned char)s;
-    const int f = fn[t * M + col];
-    s = (f >> s) & 1;
+    s = (fn[t * M + col] >> s) & 1;
   }
 }
 
@@ -228,18 +248,28 @@ __global__ void __launch_bounds__(256) pdw_edges_kernel(const float2* y, long lo
   if (!EMIT) { cnt_s[tile * M + col] = ns; cnt_e[tile * M + col] = ne; }
 }
 
-// per column exclusive prefix of the tile counts; column totals
-__global__ void pdw_offsets_kernel(int M, long long ntiles, const unsigned* cnt_s, const unsigned* cnt_e,
-                                   unsigned long long* off_s, unsigned long long* off_e, unsigned long long* tot_s,
-                                   unsigned long long* tot_e) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= M) return;
+// per column exclusive prefix of the tile counts; column totals.  One wave per column, same segment
+// decomposition as the state scan.
+__global__ void __launch_bounds__(64) pdw_offsets_kernel(int M, long long ntiles, const unsigned* cnt_s,
+                                                         const unsigned* cnt_e, unsigned long long* off_s,
+                                                         unsigned long long* off_e, unsigned long long* tot_s,
+                                                         unsigned long long* tot_e) {
+  const int col = blockIdx.x, lane = threadIdx.x;
+  const long long per = (ntiles + 63) / 64;
+  const long long t0 = lane * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
   unsigned long long a = 0, b = 0;
-  for (long long t = 0; t < ntiles; ++t) {
-    off_s[t * M + col] = a; off_e[t * M + col] = b;
-    a += cnt_s[t * M + col]; b += cnt_e[t * M + col];
+  for (long long t = t0; t < t1; ++t) { a += cnt_s[t * M + col]; b += cnt_e[t * M + col]; }
+  unsigned long long ia = a, ib = b;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long pa = __shfl_up(ia, d), pb = __shfl_up(ib, d);
+    if (lane >= d) { ia += pa; ib += pb; }
   }
-  tot_s[col] = a; tot_e[col] = b;
+  unsigned long long ea = ia - a, eb = ib - b;  // exclusive
+  for (long long t = t0; t < t1; ++t) {
+    off_s[t * M + col] = ea; off_e[t * M + col] = eb;
+    ea += cnt_s[t * M + col]; eb += cnt_e[t * M + col];
+  }
+  if (lane == 63) { tot_s[col] = ia; tot_e[col] = ib; }
 }
 
 // make the per-tile offsets absolute: add the column bases (columns outermost = the reference's order)
@@ -484,12 +514,12 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
   {
     const dim3 tgrid(cgroups, (unsigned)((ntiles + 3) / 4));
     hipLaunchKernelGGL(pdw_tilefn_kernel, tgrid, dim3(256), 0, st, d_y, F, Mi, d_thr, d_fn, ntiles);
-    hipLaunchKernelGGL(pdw_tilescan_kernel, dim3((Mi + 63) / 64), dim3(64), 0, st, Mi, ntiles, d_fn, d_state);
+    hipLaunchKernelGGL(pdw_tilescan_kernel, dim3(Mi), dim3(64), 0, st, Mi, ntiles, d_fn, d_state);
     hipLaunchKernelGGL(pdw_edges_kernel<false>, tgrid, dim3(256), 0, st, d_y, F, Mi, d_thr, d_state, ntiles, d_cnt_s, d_cnt_e,
                        (const unsigned long long*)nullptr, (const unsigned long long*)nullptr, (long long*)nullptr,
                        (long long*)nullptr);
-    hipLaunchKernelGGL(pdw_offsets_kernel, dim3((Mi + 63) / 64), dim3(64), 0, st, Mi, ntiles, d_cnt_s, d_cnt_e, d_off_s,
-                       d_off_e, d_tot, d_tot + M);
+    hipLaunchKernelGGL(pdw_offsets_kernel, dim3(Mi), dim3(64), 0, st, Mi, ntiles, d_cnt_s, d_cnt_e, d_off_s, d_off_e,
+                       d_tot, d_tot + M);
     PDW_TRY(hipGetLastError());
     PDW_TRY(hipMemcpyAsync(h_tot.data(), d_tot, 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     PDW_TRY(hipStreamSynchronize(st));
