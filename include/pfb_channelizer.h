@@ -194,7 +194,8 @@ typedef enum pfb_option {
                                 /* with the FIR and the FFT on different waves (M = 64 kernels)  */
   PFB_OPT_GRID = 7,             /* schedule 1: workgroups to launch (0 = all that are resident)  */
   PFB_OPT_TILE_WAVES = 8,       /* schedules 2/3: waves per workgroup                           */
-  PFB_OPT_EXPERIMENT = 9        /* bit mask of timing experiments; 0 in production               */
+  PFB_OPT_EXPERIMENT = 9,       /* bit mask of timing experiments; 0 in production               */
+  PFB_OPT_VARIANT = 10          /* n-th fused kernel registered for this shape (0 = default plan) */
 } pfb_option;
 int pfb_set_option(pfb_handle* h, int option, int64_t value);
 /* With PFB_OPT_PROFILE on: durations (ms) of the channelizer kernel launches

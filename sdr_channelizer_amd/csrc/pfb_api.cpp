@@ -82,6 +82,7 @@ struct pfb_handle {
   int opt_nontemporal = 0;
   int opt_xcd_remap = -1;  // -1: per schedule (on for 0..3, off for the wave-pair schedule)
   int opt_experiment = 0;
+  int opt_variant = 0;
   int opt_schedule = -1;  // -1: the instantiation's measured default
   int opt_grid = 0;
   int opt_tile_waves = 8;
@@ -598,6 +599,32 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
     case PFB_OPT_EXPERIMENT:
       h->opt_experiment = (int)value;
       return PFB_OK;
+    case PFB_OPT_VARIANT: {
+      if (value < 0 || value > 16) return PFB_ERR_BAD_ARG;
+      if ((int)value == h->opt_variant) return PFB_OK;
+      const pfb::FastKernelInfo* f = pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt, (int)value);
+      if (!f) return PFB_ERR_UNSUPPORTED;
+      DeviceGuard g(h->device);
+      HIP_TRY(hipStreamSynchronize(h->stream));  // the old tables may still be in use
+      float* tl = nullptr;
+      float2* tw = nullptr;
+      hipError_t e = hipMalloc((void**)&tl, (size_t)f->taps_lane_floats * sizeof(float));
+      if (e == hipSuccess) e = hipMalloc((void**)&tw, (size_t)f->tw_lane_elems * sizeof(float2));
+      if (e == hipSuccess) e = f->init_tables(h->d_taps, h->d_tw, tl, tw, nullptr);
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+      if (e != hipSuccess) {
+        (void)hipFree(tl);
+        (void)hipFree(tw);
+        return hip_fail(e, "pfb_set_option(PFB_OPT_VARIANT)");
+      }
+      (void)hipFree(h->d_taps_lane);
+      (void)hipFree(h->d_tw_lane);
+      h->d_taps_lane = tl;
+      h->d_tw_lane = tw;
+      h->fast = f;
+      h->opt_variant = (int)value;
+      return PFB_OK;
+    }
     case PFB_OPT_PROFILE:
       h->opt_profile = value ? 1 : 0;
       h->ev_used = 0;

@@ -325,18 +325,26 @@ struct FastKernel {
         if (active && f < p.frames) {
           const bool flip_odd = (OS == 2) && (p.flags & PFB_FLAG_DEROTATE) && ((p.frame0 + f) & 1);
           const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
-          // fftshift(out,2): column (k + M/2) mod M; an XOR when M is a power of two
+          // fftshift(out,2): column (k + M/2) mod M.  For a power-of-two M that swaps the two halves of
+          // the row, and since KK * R == M the butterfly outputs k < R/2 land in one half and k >= R/2 in
+          // the other: two base pointers plus compile-time offsets instead of one address per store.
           auto col_of = [&](int ch) {
-            if constexpr (K::POW2) return ch ^ shift;
-            else { const int c2 = ch + shift; return c2 >= M ? c2 - M : c2; }
+            const int c2 = ch + shift;
+            return c2 >= M ? c2 - M : c2;
+          };
+          auto slot = [&](auto* rowp, int k) {
+            if constexpr (K::POW2) {
+              auto* lo = rowp + kk + shift;
+              auto* hi = rowp + kk + (M / 2 - shift);
+              return (k < R / 2) ? lo + k * KK : hi + (k - R / 2) * KK;
+            } else {
+              return rowp + col_of(kk + k * KK);
+            }
           };
           if (p.flags & PFB_FLAG_MAGNITUDE) {  // fused abs(): 4 bytes per channel instead of 8
             float* rowm = reinterpret_cast<float*>(p.out) + f0 * M + fc * M;
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-              const int ch = kk + k * KK;
-              rowm[col_of(ch)] = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
-            }
+            for (int k = 0; k < R; ++k) *slot(rowm, k) = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
           } else {
             float2* row = p.out + f0 * M + fc * M;
 #pragma unroll
@@ -344,7 +352,7 @@ struct FastKernel {
               const int ch = kk + k * KK;
               v2f v = x[k];
               if (flip_odd && (ch & 1)) v = -v;
-              store_c64(&row[col_of(ch)], v, p.nontemporal);
+              store_c64(slot(row, k), v, p.nontemporal);
             }
           }
         }

@@ -205,6 +205,13 @@ using Cfg256x8i16 = FastCfg<256, 8, 256, 4, PFB_FMT_INT16_IQ, 4, 2, 16, 16, 1, 1
 using Cfg1024x16i16 =
     FastCfg<1024, 16, 1024, 2, PFB_FMT_INT16_IQ, 8, 3, 16, 16, 4, 64, 68, 260, 1088, false, 2, true>;
 
+// cfg4, second plan: 1024 threads x 1 column (16 waves per CU instead of 8: the window is half as many
+// registers per thread), 1024 = 8 x 8 x 16, conflict-free padding
+using Cfg1024x16i16b =
+    FastCfg<1024, 16, 1024, 1, PFB_FMT_INT16_IQ, 8, 3, 8, 8, 16, 128, 128, 65, 1040, false, 1, true>;
+
+
+
 // the reference's own band count: numBands = fs*1e-6 = 56 (channelizer_example.m:29, generate_pulsed_iq.m:12),
 // 56 = 8 x 7; 56 of the wave's 64 lanes own columns (2-way LDS conflicts on about half the accesses)
 using Cfg56x12i16 = FastCfg<56, 12, 56, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
@@ -226,14 +233,15 @@ static const FastEntry kFastTable[] = {
     entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 512, 0),
     entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 256, 0),
     entry<Cfg256x8i16>("pfb_fast<M256,P8,D256,int16>", 256, 0),
-    entry<Cfg1024x16i16>("pfb_fast<M1024,P16,D1024,int16>", 256, 0),
+    entry<Cfg1024x16i16b>("pfb_fast<M1024,P16,D1024,int16>", 256, 0),
+    entry<Cfg1024x16i16>("pfb_fast<M1024,P16,D1024,int16,8w>", 256, 0),
     entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 0),
     entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 0),
 };
 
-const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt) {
+const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant) {
   for (const FastEntry& e : kFastTable)
-    if (e.M == M && e.P == P && e.D == D && e.fmt == fmt) return &e.info;
+    if (e.M == M && e.P == P && e.D == D && e.fmt == fmt && variant-- == 0) return &e.info;
   return nullptr;
 }
 
