@@ -156,6 +156,44 @@ template <> struct Dft<7> {
   }
 };
 
+// 5- and 10-point DFTs: the reference's other band count is round(fs / 0.1e6) = 560 = 10 x 8 x 7
+// (generate_channelized_training_iq.m:95-96).  Same pairing as the 7-point one.
+template <> struct Dft<5> {
+  PFB_DEV void run(v2f (&x)[5]) {
+    constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+    constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    const v2f p1 = x[1] + x[4], p2 = x[2] + x[3];
+    const v2f d1 = x[1] - x[4], d2 = x[2] - x[3];
+    const v2f x0 = x[0];
+    const v2f a1 = fma2(p2, splat(c2), fma2(p1, splat(c1), x0));
+    const v2f a2 = fma2(p2, splat(c1), fma2(p1, splat(c2), x0));
+    const v2f b1 = fma2(d2, splat(s2), d1 * splat(s1));
+    const v2f b2 = fma2(d2, splat(-s1), d1 * splat(s2));
+    x[0] = x0 + p1 + p2;
+    x[1] = add_j(a1, b1); x[4] = sub_j(a1, b1);
+    x[2] = add_j(a2, b2); x[3] = sub_j(a2, b2);
+  }
+};
+
+template <> struct Dft<10> {
+  PFB_DEV void run(v2f (&x)[10]) {
+    // W_10^k = e^{+j 2 pi k / 10}
+    constexpr float c1 = 0.80901699437494742f, s1 = 0.58778525229247313f;
+    constexpr float c2 = 0.30901699437494742f, s2 = 0.95105651629515357f;
+    v2f e[5], o[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { e[k] = x[2 * k]; o[k] = x[2 * k + 1]; }
+    Dft<5>::run(e);
+    Dft<5>::run(o);
+    const v2f t1 = cmul(o[1], c1, s1), t2 = cmul(o[2], c2, s2), t3 = cmul(o[3], -c2, s2), t4 = cmul(o[4], -c1, s1);
+    x[0] = e[0] + o[0]; x[5] = e[0] - o[0];
+    x[1] = e[1] + t1;   x[6] = e[1] - t1;
+    x[2] = e[2] + t2;   x[7] = e[2] - t2;
+    x[3] = e[3] + t3;   x[8] = e[3] - t3;
+    x[4] = e[4] + t4;   x[9] = e[4] - t4;
+  }
+};
+
 template <int N, int K>
 struct DftCombine {
   PFB_DEV void run(v2f (&x)[N], const v2f (&e)[N / 2], const v2f (&o)[N / 2]) {

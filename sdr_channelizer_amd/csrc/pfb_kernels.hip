@@ -217,6 +217,15 @@ using Cfg1024x16i16b =
 using Cfg56x12i16 = FastCfg<56, 12, 56, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
 using Cfg56x12i8  = FastCfg<56, 12, 56, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
 
+// the reference's training-set band count: numBands = round(fs / 0.1e6) = 560 at fs = 56 MHz
+// (generate_channelized_training_iq.m:95-96).  560 = 10 x 8 x 7; 560 of 576 threads own columns; chunks
+// of 7 frames make every pass one iteration (7 * 80 = 560 final-pass items); at most 2-way LDS conflicts
+// on about a third of the accesses (no padding removes them for this size, tools/fft_plan_model.py)
+using Cfg560x12i16 =
+    FastCfg<560, 12, 560, 1, PFB_FMT_INT16_IQ, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;
+using Cfg560x12i8 =
+    FastCfg<560, 12, 560, 1, PFB_FMT_INT8_IQ, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;
+
 struct FastEntry { int M, P, D, fmt; FastKernelInfo info; };
 
 template <class K>
@@ -237,6 +246,8 @@ static const FastEntry kFastTable[] = {
     entry<Cfg1024x16i16>("pfb_fast<M1024,P16,D1024,int16,8w>", 256, 0),
     entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 0),
     entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 0),
+    entry<Cfg560x12i16>("pfb_fast<M560,P12,D560,int16>", 252, 0),
+    entry<Cfg560x12i8>("pfb_fast<M560,P12,D560,int8>", 252, 0),
 };
 
 const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant) {

@@ -14,8 +14,10 @@ One fixture per BASELINE.json config shape at reduced N:
   cfg4  M=1024 P=16 D=1024 int16, 16-bit   (usrp_record_iq_12bit: sc16 host format)
   cfg5  M=128  P=12 D=64   int16, 12-bit   (2x oversampled)
   ref56 M=56   P=12 D=56   int16, 12-bit   (the reference's own M = fs*1e-6)
+  ref560 M=560 P=12 D=560  int16, 12-bit   (its training-set M = round(fs/0.1e6),
+                                            generate_channelized_training_iq.m:95-96)
 
-Run from the repo root:  python tests/golden/make_golden.py
+Run from the repo root:  python tests/golden/make_golden.py [name ...]   (default: all)
 """
 import os
 import sys
@@ -37,12 +39,14 @@ CASES = {
     "cfg4": (1024, 16, 1024, "int16", 16, 40),
     "cfg5": (128, 12, 64, "int16", 12, 160),
     "ref56": (56, 12, 56, "int16", 12, 96),
+    "ref560": (560, 12, 560, "int16", 12, 24),
 }
 
 
 def main():
     o = COracle()
-    for name, (M, P, D, fmt, bw, frames) in CASES.items():
+    for name in (sys.argv[1:] or list(CASES)):
+        M, P, D, fmt, bw, frames = CASES[name]
         n = frames * D
         h = o.design_prototype(M, P, 80.0).astype(np.float32)  # what the product is handed
         if fmt == "cf32":

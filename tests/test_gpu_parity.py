@@ -32,7 +32,7 @@ def oracle_run(oracle, iq, h, M, P, D, bw, fmt="int", **kw):
 FMT_NAME = {"int8": "int8", "int16": "int16", "cf32": "cf32"}
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "ref56"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "ref56", "ref560"])
 @pytest.mark.parametrize("kernel", [0, 1])
 def test_golden_fixtures(golden_dir, name, kernel):
     g = np.load(os.path.join(golden_dir, f"{name}.npz"))
@@ -57,7 +57,8 @@ def test_cfg2_uses_the_fast_kernel(golden_dir):
 
 @pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (64, 12, 64, "int8", 8), (256, 8, 256, "int8", 8),
                                           (128, 12, 64, "int16", 12), (1024, 16, 1024, "int16", 16),
-                                          (56, 12, 56, "int16", 12), (8, 12, 8, "int16", 12)])
+                                          (56, 12, 56, "int16", 12), (8, 12, 8, "int16", 12),
+                                          (560, 12, 560, "int16", 12), (560, 12, 560, "int8", 8)])
 @pytest.mark.parametrize("q0", [0, 3])
 def test_one_hot_tap_bit_exact(M, P, D, fmt, bw, q0):
     """h = delta[n - M q0] => every channel of frame m equals x[mD + D-1 - M q0] exactly:
@@ -81,7 +82,7 @@ def test_one_hot_tap_bit_exact(M, P, D, fmt, bw, q0):
     (64, 12, 64, "int16", 12, 1 << 18), (64, 12, 64, "int8", 8, 1 << 16), (64, 12, 64, "cf32", 0, 1 << 16),
     (256, 8, 256, "int8", 8, 1 << 17), (128, 12, 64, "int16", 12, 1 << 16), (1024, 16, 1024, "int16", 16, 1 << 18),
     (32, 12, 32, "int16", 12, 1 << 14), (16, 4, 8, "int16", 16, 1 << 12), (56, 12, 56, "int16", 12, 56 * 300),
-    (12, 5, 4, "int8", 8, 4 * 500)])
+    (12, 5, 4, "int8", 8, 4 * 500), (560, 12, 560, "int16", 12, 560 * 150 + 31), (560, 12, 560, "int8", 8, 560 * 64)])
 def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     rng = np.random.default_rng(n + M)
     if fmt == "cf32":
@@ -95,7 +96,7 @@ def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     assert rel(y, want) < REL_TOL
 
 
-@pytest.mark.parametrize("M,P,D", [(64, 12, 64), (128, 12, 64), (56, 12, 56)])
+@pytest.mark.parametrize("M,P,D", [(64, 12, 64), (128, 12, 64), (56, 12, 56), (560, 12, 560)])
 @pytest.mark.parametrize("kw", [dict(fftshift=True), dict(conjugate_input=True), dict(derotate=True),
                                 dict(input_offset=0), dict(input_offset=5),
                                 dict(fftshift=True, conjugate_input=True, derotate=True)])
@@ -124,7 +125,7 @@ def test_channel_major_layout(oracle, M, P, D):
 
 
 @pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (128, 12, 64, "int16", 12), (56, 12, 56, "int16", 12),
-                                          (256, 8, 256, "int8", 8)])
+                                          (256, 8, 256, "int8", 8), (560, 12, 560, "int16", 12)])
 def test_chunked_equals_one_shot_bit_exact(M, P, D, fmt, bw):
     """The handle is stateful like the System object (channelizer_example.m:50-56): any split of
     the stream -- including pieces that are not multiples of D -- gives identical bits."""
@@ -259,7 +260,7 @@ def test_device_tensor_path_matches_host_path():
 
 @pytest.mark.parametrize("M,P,D,fmt,bw,log2n", [(64, 12, 64, "int16", 12, 30), (256, 8, 256, "int8", 8, 30),
                                                 (1024, 16, 1024, "int16", 16, 28), (128, 12, 64, "int16", 12, 28),
-                                                (56, 12, 56, "int16", 12, 26)])
+                                                (56, 12, 56, "int16", 12, 26), (560, 12, 560, "int16", 12, 26)])
 def test_large_stream_interior_windows(oracle, M, P, D, fmt, bw, log2n):
     """BASELINE.json's full sizes through size-independent checks: run the whole synthetic stream
     (generated in HBM), then compare random interior frame windows -- plus the first and last frames and
@@ -324,7 +325,8 @@ def test_every_schedule_gives_identical_bits(oracle, opts):
 
 @pytest.mark.parametrize("M,P,D,fmt,bw,kw", [(64, 12, 64, "int16", 12, {}), (128, 12, 64, "int16", 12, {}),
                                              (256, 8, 256, "int8", 8, {}), (1024, 16, 1024, "int16", 16, {}),
-                                             (56, 12, 56, "int16", 12, {}), (64, 12, 64, "int16", 12, dict(channel_major=True))])
+                                             (56, 12, 56, "int16", 12, {}), (64, 12, 64, "int16", 12, dict(channel_major=True)),
+                                             (560, 12, 560, "int16", 12, {})])
 def test_fused_magnitude_output(oracle, M, P, D, fmt, bw, kw):
     """PFB_FLAG_MAGNITUDE = abs(channelizer(x)) of channelizer_example.m:56, fused into the store."""
     n = D * 300

@@ -141,13 +141,13 @@ def test_prototype_design(oracle):
     assert h.size == 96 and h.argmax() == 48 and abs(h.sum() - 1.0) < 1e-3
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "ref56"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "ref56", "ref560"])
 def test_golden_fixtures_reproduce(oracle, golden_dir, name):
     g = np.load(os.path.join(golden_dir, f"{name}.npz"))
     M, P, D, bw = int(g["M"]), int(g["P"]), int(g["D"]), int(g["bit_width"])
     iq = g["iq"]
     x = (iq[:, 0].astype(np.float64) + 1j * iq[:, 1]) if str(g["fmt"]) == "cf32" else oracle.unpack(iq, bw)
-    method = "fft" if M >= 256 else "polyphase"
+    method = "fft" if (M >= 256 and (M & (M - 1)) == 0) else "polyphase"
     y = oracle.channelize(x, g["taps"].astype(np.float64), OracleConfig(M, P, D), method)
     assert y.shape == g["expected"].shape
     assert rel(y, g["expected"]) < 1e-12
