@@ -245,6 +245,13 @@ int pfb_pdw_extract(const void* y, uint64_t frames, uint32_t num_channels, uint3
                     double* noise_floor_out, uint32_t mem, int32_t device_id, void* hip_stream);
 /* Text of the most recent HIP failure inside pfb_pdw_extract on this thread. */
 const char* pfb_pdw_last_error_detail(void);
+/* How the last pfb_pdw_extract on this thread found the noise floors: 1 = sampled bracket + one
+ * pass, 2 = full radix select (short input), 3 = the bracket check failed (heavily tied data) and
+ * the full radix select ran after it.  All three give the exact medians; diagnostic only. */
+int pfb_pdw_last_noise_floor_path(void);
+/* pfb_pdw_extract keeps its device scratch between calls (grow-only, per device; calls are
+ * serialised on it).  This frees it: device_id >= 0 for one device, < 0 for all. */
+int pfb_pdw_release_workspace(int32_t device_id);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,34 @@ def test_degenerate_all_equal_magnitudes(oracle):
     compare(got, want, 1e6)
 
 
+def big_matrix(F, M, seed, levels=0):
+    rng = np.random.default_rng(seed)
+    y = (0.01 * (rng.standard_normal((F, M), dtype=np.float32) + 1j * rng.standard_normal((F, M), dtype=np.float32)))
+    if levels:  # magnitudes on a coarse grid: most of a channel's values are tied
+        y = (np.round(y.real * levels) / levels + 1j * np.round(y.imag * levels) / levels)
+    y = y.astype(np.complex64)
+    for b, a, n in ((1, 1000, 90), (1, 300000, 90), (M - 2, 500000, 2000), (M // 2, F - 3000, 100)):
+        y[a:a + n, b] += (0.5 * np.exp(1j * np.deg2rad(33.0) * np.arange(n))).astype(np.complex64)
+    return y
+
+
+@pytest.mark.parametrize("F,M,levels,path", [(600000, 24, 0, 1), (600001, 70, 0, 1), (600000, 8, 200, 3)])
+def test_long_streams_take_the_sampled_bracket_and_stay_exact(oracle, F, M, levels, path):
+    """F >= 8 * 65536 frames: the noise floor comes from the sampled bracket + one pass (path 1); data too tied
+    for the bracket (a coarse amplitude grid) fail its count check and fall back to the full select (path 3).
+    Either way the medians are the exact ones."""
+    from sdr_channelizer_amd import _lib as L
+    y = big_matrix(F, M, seed=F % 97 + M, levels=levels)
+    got, nf = extract_pdws(y, 8e6, 1e9, 0.0, return_noise_floor=True)
+    assert L.load().pfb_pdw_last_noise_floor_path() == path
+    mag = np.abs(y.astype(np.complex128))
+    assert np.allclose(nf, np.median(mag, axis=0), rtol=1e-12, atol=0)
+    want = oracle.extract_pdws(y.astype(np.complex128), 8e6, 1e9, 0.0, 15.0)
+    compare(got, want, 8e6 / M)
+    assert len(want) >= 3
+    L.load().pfb_pdw_release_workspace(-1)
+
+
 def test_capacity_overflow_is_reported():
     y = synthetic_matrix()
     with pytest.raises(OverflowError):
