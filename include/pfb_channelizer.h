@@ -226,6 +226,8 @@ typedef struct pfb_pdw {
   double snr;   /* dB (:105)                                                             */
   int32_t sat;  /* 0/1 (:130-132)                                                        */
   int32_t bin;  /* 0-based (shifted) column the pulse was found in                       */
+  double mag;   /* median magnitude over the pulse: thisAmp (:101; the channelized script
+                   does not store it) / pdw.mag of matlab/create_pdws.m:70,96            */
 } pfb_pdw;
 
 enum {
@@ -243,6 +245,19 @@ int pfb_pdw_extract(const void* y, uint64_t frames, uint32_t num_channels, uint3
                     double fs_in, double fc, double sample_start_time, double snr_threshold_db,
                     uint32_t flags, pfb_pdw* out, uint64_t capacity, uint64_t* count,
                     double* noise_floor_out, uint32_t mem, int32_t device_id, void* hip_stream);
+/* ---- raw (un-channelized) PDW extraction -----------------------------------------
+ * Replaces matlab/create_pdws.m:30-105: the same extraction on the recorder stream itself.
+ * x = (I + jQ) / 2^(bit_width-1) (:30-33); ONE noise floor = median |x| (:44); a pulse starts at
+ * |x| >= NF*10^(snr_threshold_db/10) (:45-46,57) and ends at |x| <= NF*10^(trailing_threshold_db/10)
+ * (:47,63) -- the script uses 18 and 3 dB; trailing must not exceed leading.  Per pulse: toa (:67),
+ * mag (:70), snr (:74), pw (:79), freq = fc + fs/(360/median wrapped phase step) (:83-91), sat
+ * (:100-102); bin is 0.  `iq` is interleaved I,Q in `sample_format` (PFB_FMT_*), host or device per
+ * `mem`; fs is the sample rate; noise_floor_out (optional) receives the one median.  *count receives
+ * the number of pulses found even when it exceeds capacity. */
+int pfb_pdw_extract_raw(const void* iq, uint64_t num_samples, uint32_t sample_format, uint32_t bit_width,
+                        double fs, double fc, double sample_start_time, double snr_threshold_db,
+                        double trailing_threshold_db, pfb_pdw* out, uint64_t capacity, uint64_t* count,
+                        double* noise_floor_out, uint32_t mem, int32_t device_id, void* hip_stream);
 /* Text of the most recent HIP failure inside pfb_pdw_extract on this thread. */
 const char* pfb_pdw_last_error_detail(void);
 /* How the last pfb_pdw_extract on this thread found the noise floors: 1 = sampled bracket + one

@@ -458,6 +458,7 @@ size_t pfbo_extract_pdws(const double* yr, const double* yi, size_t F, int M, in
           o->freq = fc_chan + (fs / (360.0 / med));            /* :122 */
           o->sat = saturated;
           o->bin = b;
+          o->mag = amp;
         }
         ++count;
       } else {
@@ -470,5 +471,57 @@ size_t pfbo_extract_pdws(const double* yr, const double* yi, size_t F, int M, in
 #undef PHASE
   free(tmp);
   free(nf);
+  return count;
+}
+
+/* matlab/create_pdws.m:30-105: the same state machine on the raw stream, with hysteresis. */
+size_t pfbo_extract_pdws_raw(const double* xr, const double* xi, size_t n, double fs, double fc,
+                             double sample_start_time, double snr_threshold_db, double trailing_threshold_db,
+                             pfbo_pdw* out, size_t max_out, double* noise_floor) {
+  double* tmp = (double*)malloc(sizeof(double) * (n + 1));
+  if (!tmp) return 0;
+#define MAG(j) hypot(xr[j], xi[j])                         /* :38 */
+#define PHASE(j) (atan2(xi[j], xr[j]) * (180.0 / M_PI))    /* :39 */
+  for (size_t j = 0; j < n; ++j) tmp[j] = MAG(j);
+  const double nf = median_of(tmp, n);                                        /* :44 */
+  const double lead = nf * pow(10.0, snr_threshold_db / 10.0);                /* :45-46 */
+  const double trail = nf * pow(10.0, trailing_threshold_db / 10.0);          /* :47 */
+  if (noise_floor) *noise_floor = nf;
+  size_t count = 0, toa = 0;
+  int active = 0, saturated = 0;
+  for (size_t j = 0; j < n; ++j) {
+    const double mg = MAG(j);
+    if (!active) {
+      if (mg >= lead) { active = 1; toa = j; saturated = 0; }                 /* :57-60 */
+    } else if (mg <= trail) {                                                 /* :63 */
+      active = 0;
+      const size_t len = j - toa + 1;
+      for (size_t t = 0; t < len; ++t) tmp[t] = MAG(toa + t);
+      const double amp = median_of(tmp, len);                                 /* :70 */
+      for (size_t t = 0; t + 1 < len; ++t) {
+        double d = PHASE(toa + t + 1) - PHASE(toa + t);                       /* :83 */
+        if (d < -180.0) d += 360.0;                                           /* :84 */
+        if (d > 180.0) d -= 360.0;                                            /* :85 */
+        tmp[t] = d;
+      }
+      const double med = median_of(tmp, len - 1);                             /* :86 */
+      if (count < max_out) {
+        pfbo_pdw* o = &out[count];
+        o->toa = ((double)(toa + 1) / fs) + sample_start_time;                /* :67, 1-based index */
+        o->mag = amp;
+        o->snr = 10.0 * log10(amp / nf);                                      /* :74 */
+        o->pw = (double)(j - toa) / fs;                                       /* :79 */
+        o->freq = fc + (fs / (360.0 / med));                                  /* :91 */
+        o->sat = saturated;
+        o->bin = 0;
+      }
+      ++count;
+    } else if (fabs(xr[j]) >= 0.9999 || fabs(xi[j]) >= 0.9999) {             /* :100-102 */
+      saturated = 1;
+    }
+  }
+#undef MAG
+#undef PHASE
+  free(tmp);
   return count;
 }

@@ -132,6 +132,8 @@ typedef struct {
   double snr;   /* dB (:105)           */
   int    sat;   /* (:130-132)          */
   int    bin;   /* 0-based shifted column the pulse was found in (extra) */
+  double mag;   /* median magnitude over the pulse: thisAmp (:101, not stored by the channelized
+                   script) / thisMag (create_pdws.m:70,96) */
 } pfbo_pdw;
 
 /* y: F x M complex, frame-major, already fftshift-ed (:60). fs_in is the rate
@@ -146,6 +148,15 @@ size_t pfbo_extract_pdws(const double* yr, const double* yi, size_t F, int M, in
                          double fs_in, double fc, double sample_start_time,
                          double snr_threshold_db, int matlab_quirks,
                          pfbo_pdw* out, size_t max_out);
+
+/* ---- raw (un-channelized) PDW extraction (matlab/create_pdws.m:30-105) ---------------- */
+/* x: n complex samples already normalised to [-1, 1) (:30-33).  One noise floor = median |x| (:44);
+ * leading edge at |x| >= NF*10^(snr_db/10) (:45-46,57), trailing edge at |x| <= NF*10^(trail_db/10)
+ * (:47,63); the reference uses 18 and 3.  fs is the sample rate (no decimation).  bin is 0.
+ * If noise_floor is not NULL it receives NF.  Returns the number of PDWs found. */
+size_t pfbo_extract_pdws_raw(const double* xr, const double* xi, size_t n, double fs, double fc,
+                             double sample_start_time, double snr_threshold_db, double trailing_threshold_db,
+                             pfbo_pdw* out, size_t max_out, double* noise_floor);
 
 #ifdef __cplusplus
 }

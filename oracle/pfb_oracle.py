@@ -54,7 +54,7 @@ class _IqHeader(C.Structure):
 
 class _Pdw(C.Structure):
     _fields_ = [("toa", C.c_double), ("freq", C.c_double), ("pw", C.c_double),
-                ("snr", C.c_double), ("sat", C.c_int), ("bin", C.c_int)]
+                ("snr", C.c_double), ("sat", C.c_int), ("bin", C.c_int), ("mag", C.c_double)]
 
 
 @dataclass
@@ -106,6 +106,9 @@ class COracle:
         lib.pfbo_extract_pdws.restype = C.c_size_t
         lib.pfbo_extract_pdws.argtypes = [_dp, _dp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                           C.c_double, C.c_int, C.POINTER(_Pdw), C.c_size_t]
+        lib.pfbo_extract_pdws_raw.restype = C.c_size_t
+        lib.pfbo_extract_pdws_raw.argtypes = [_dp, _dp, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
+                                              C.c_double, C.POINTER(_Pdw), C.c_size_t, C.POINTER(C.c_double)]
 
     # -- a3 -------------------------------------------------------------------
     def unpack(self, iq: np.ndarray, bit_width: int) -> np.ndarray:
@@ -187,7 +190,21 @@ class COracle:
         n = self.lib.pfbo_extract_pdws(yr, yi, F, M, M if decim is None else decim, fs_in, fc, start_time, snr_db,
                                        int(matlab_quirks), buf, max_out)
         n = min(int(n), max_out)
-        return [dict(toa=b.toa, freq=b.freq, pw=b.pw, snr=b.snr, sat=bool(b.sat), bin=b.bin) for b in buf[:n]]
+        return [dict(toa=b.toa, freq=b.freq, pw=b.pw, snr=b.snr, sat=bool(b.sat), bin=b.bin, mag=b.mag) for b in buf[:n]]
+
+    def extract_pdws_raw(self, x: np.ndarray, fs: float, fc: float, start_time: float, snr_db: float = 18.0,
+                         trail_db: float = 3.0, max_out: int = 1 << 16):
+        """matlab/create_pdws.m:30-105 on normalised complex samples x.  Returns (pdws, noise_floor)."""
+        x = np.asarray(x, dtype=np.complex128).reshape(-1)
+        xr = np.ascontiguousarray(x.real)
+        xi = np.ascontiguousarray(x.imag)
+        buf = (_Pdw * max_out)()
+        nf = C.c_double(0.0)
+        n = self.lib.pfbo_extract_pdws_raw(xr, xi, x.size, fs, fc, start_time, snr_db, trail_db, buf, max_out,
+                                           C.byref(nf))
+        n = min(int(n), max_out)
+        return ([dict(toa=b.toa, freq=b.freq, pw=b.pw, snr=b.snr, sat=bool(b.sat), bin=b.bin, mag=b.mag)
+                 for b in buf[:n]], nf.value)
 
 
 class RefIqPacket:

@@ -59,6 +59,22 @@ __device__ __forceinline__ double dkey_inv(unsigned long long k) {
   return __longlong_as_double((long long)b);
 }
 
+// histogram increment with a wave-uniform fast path: when every participating lane of the wave has the
+// same digit (the common case while the decided prefix is still shared by all values) one lane adds the
+// lane count instead of 64 atomics serialising on one LDS word.  Lanes with pred == false do not count.
+__device__ __forceinline__ void hist_add(unsigned* h, unsigned digit, bool pred) {
+  const unsigned long long act = __ballot(pred);
+  if (!act) return;
+  const int leader = __ffsll((long long)act) - 1;
+  const unsigned d0 = (unsigned)__shfl((int)digit, leader);
+  const unsigned long long same = __ballot(pred && digit == d0);
+  if (same == act) {
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[d0], (unsigned)__popcll(act));
+  } else if (pred) {
+    atomicAdd(&h[digit], 1u);
+  }
+}
+
 // k-th smallest of n doubles produced by get(i), by 8 passes of 8-bit digits; the whole workgroup
 // cooperates (every thread must call it, with the same n and k).  The digit holding rank k is found by
 // wave 0: four counters per lane, a shuffle scan, one lane owns the answer.
@@ -70,9 +86,11 @@ __device__ double block_select(Get get, long long n, long long k, unsigned* hist
     const int shift = 56 - 8 * pass;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0u;
     __syncthreads();
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-      const unsigned long long key = dkey(get(i));
-      if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+    for (long long i0 = 0; i0 < n; i0 += blockDim.x) {  // uniform trip count: hist_add uses wave-wide votes
+      const long long i = i0 + threadIdx.x;
+      const unsigned long long key = (i < n) ? dkey(get(i)) : 0ull;
+      const bool in = (i < n) && (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8)));
+      hist_add(hist, (unsigned)(key >> shift) & 255u, in);
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -352,36 +370,88 @@ __global__ void __launch_bounds__(1024) pdw_bracket_finish_kernel(long long F, c
 
 // ---------------------------------------------------------------------------------
 // edges
+//
+// The leading/trailing-edge state machine (create_pdws_channelized.m:85-135, create_pdws.m:54-105) is a
+// 2-state automaton driven by two comparisons per sample: inactive -> active on mag >= lead (:87 / :57),
+// active stays active while mag > trail (:94 / :63; the channelized script has lead == trail).  One pass
+// over the data records the two comparison bits per sample (64 samples per word); everything after that
+// -- tile summaries, the scan, the edge lists -- works on the bit masks, 1/64 of the data.
 
-// automaton step of create_pdws_channelized.m:85-135: inactive -> active on mag >= thr (:87),
-// active -> inactive on mag <= thr (:94)
-__device__ __forceinline__ int step_state(int active, double m, double thr) {
-  return active ? (m > thr) : (m >= thr);
+constexpr int kTileWords = kTile / 64;
+
+// Per-sample transition functions of one word: sample i maps state s to (s ? f1 : f0) bit i.  Returns the
+// prefix compositions: bit i of p0 / p1 = state after sample i when the word is entered inactive / active
+// (Kogge-Stone over function composition; bit 0 is the earliest sample).
+__device__ __forceinline__ void word_scan(unsigned long long f0, unsigned long long f1, unsigned long long& p0,
+                                          unsigned long long& p1) {
+  p0 = f0;
+  p1 = f1;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long e0 = p0 << d, e1 = (p1 << d) | ((1ull << d) - 1ull);  // earlier span; identity shifted in
+    const unsigned long long n0 = (e0 & p1) | (~e0 & p0), n1 = (e1 & p1) | (~e1 & p0);
+    p0 = n0;
+    p1 = n1;
+  }
+}
+
+// comparison masks of the F x M matrix, laid out [word][channel].  grid = (column groups, word groups of
+// 4): one word (64 frames) per wave, lane = channel.  Frames past F are the identity (f0 = 0, f1 = 1).
+__global__ void __launch_bounds__(256) pdw_mask_kernel(const float2* y, long long F, int M, const double* thr,
+                                                       unsigned long long* f0, unsigned long long* f1, long long words) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const long long w = (long long)blockIdx.y * 4 + wave;
+  if (col >= M || w >= words) return;
+  const double t = thr[col];
+  const long long r0 = w * 64;
+  unsigned long long a = 0ull, b = 0ull;
+  if (r0 + 64 <= F) {
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+      const double m = mag_of(y[(r0 + i) * M + col]);
+      a |= (unsigned long long)(m >= t) << i;
+      b |= (unsigned long long)(m > t) << i;
+    }
+  } else {
+    for (int i = 0; i < 64; ++i) {
+      if (r0 + i < F) {
+        const double m = mag_of(y[(r0 + i) * M + col]);
+        a |= (unsigned long long)(m >= t) << i;
+        b |= (unsigned long long)(m > t) << i;
+      } else {
+        b |= 1ull << i;
+      }
+    }
+  }
+  f0[w * M + col] = a;
+  f1[w * M + col] = b;
 }
 
 // tile summaries for BOTH incoming states: fn[tile][col] = f(0) | f(1) << 1 and the edge counts of either
-// trajectory, cnt[tile][col] = (starts from 0, ends from 0, starts from 1, ends from 1).  With the counts
-// of both trajectories in hand no second counting pass over the data is needed once the scan has told
-// which state each tile really starts in.  grid = (column groups, tile groups of 4), one tile per wave
-__global__ void __launch_bounds__(256) pdw_tilefn_kernel(const float2* y, long long F, int M, const double* thr,
-                                                         unsigned char* fn, ushort4* cnt, long long ntiles) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
-  const long long tile = (long long)blockIdx.y * 4 + wave;
-  if (col >= M || tile >= ntiles) return;
-  const double t = thr[col];
-  const long long r0 = tile * kTile, r1 = (r0 + kTile < F) ? r0 + kTile : F;
+// trajectory, cnt[tile][col] = (starts from 0, ends from 0, starts from 1, ends from 1): with both in
+// hand nothing has to be recounted once the scan has told which state each tile really starts in.
+// One thread per (tile, channel), channel fastest.
+__global__ void __launch_bounds__(256) pdw_tilefn_kernel(const unsigned long long* f0, const unsigned long long* f1, int M,
+                                                         long long ntiles, unsigned char* fn, ushort4* cnt) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= ntiles * M) return;
+  const int col = (int)(g % M);
+  const long long tile = g / M;
   int s0 = 0, s1 = 1;
   unsigned a0 = 0, e0 = 0, a1 = 0, e1 = 0;
-  for (long long r = r0; r < r1; ++r) {
-    const double m = mag_of(y[r * M + col]);
-    const int n0 = step_state(s0, m, t), n1 = step_state(s1, m, t);
-    a0 += (unsigned)((s0 ^ 1) & n0); e0 += (unsigned)(s0 & (n0 ^ 1));
-    a1 += (unsigned)((s1 ^ 1) & n1); e1 += (unsigned)(s1 & (n1 ^ 1));
-    s0 = n0; s1 = n1;
+  for (int j = 0; j < kTileWords; ++j) {
+    const long long w = tile * kTileWords + j;
+    unsigned long long p0, p1;
+    word_scan(f0[w * M + col], f1[w * M + col], p0, p1);
+    const unsigned long long S0 = s0 ? p1 : p0, S1 = s1 ? p1 : p0;
+    const unsigned long long P0 = (S0 << 1) | (unsigned long long)s0, P1 = (S1 << 1) | (unsigned long long)s1;
+    a0 += (unsigned)__popcll(S0 & ~P0); e0 += (unsigned)__popcll(~S0 & P0);
+    a1 += (unsigned)__popcll(S1 & ~P1); e1 += (unsigned)__popcll(~S1 & P1);
+    s0 = (int)(S0 >> 63); s1 = (int)(S1 >> 63);
   }
-  fn[tile * M + col] = (unsigned char)(s0 | (s1 << 1));
-  cnt[tile * M + col] = make_ushort4((unsigned short)a0, (unsigned short)e0, (unsigned short)a1, (unsigned short)e1);
+  fn[g] = (unsigned char)(s0 | (s1 << 1));
+  cnt[g] = make_ushort4((unsigned short)a0, (unsigned short)e0, (unsigned short)a1, (unsigned short)e1);
 }
 
 // per column: incoming state of every tile, then the exclusive prefix of the edge counts of the
@@ -435,27 +505,26 @@ __global__ void __launch_bounds__(64) pdw_tilescan_kernel(int M, long long ntile
   if (lane == 63) { tot_s[col] = ia; tot_e[col] = ib; }
 }
 
-// replay a tile from its incoming state and write the leading / trailing edge frame indices
-__global__ void __launch_bounds__(256) pdw_edges_kernel(const float2* y, long long F, int M, const double* thr,
-                                                        const unsigned char* state_in, long long ntiles,
+// replay a tile from its incoming state and write the leading / trailing edge sample indices
+__global__ void __launch_bounds__(256) pdw_edges_kernel(const unsigned long long* f0, const unsigned long long* f1, int M,
+                                                        long long ntiles, const unsigned char* state_in,
                                                         const unsigned long long* off_s, const unsigned long long* off_e,
                                                         long long* starts, long long* ends) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
-  const long long tile = (long long)blockIdx.y * 4 + wave;
-  if (col >= M || tile >= ntiles) return;
-  const double t = thr[col];
-  const long long r0 = tile * kTile, r1 = (r0 + kTile < F) ? r0 + kTile : F;
-  int s = state_in[tile * M + col];
-  unsigned long long os = off_s[tile * M + col], oe = off_e[tile * M + col];
-  for (long long r = r0; r < r1; ++r) {
-    const double m = mag_of(y[r * M + col]);
-    const int n = step_state(s, m, t);
-    if (n != s) {
-      if (n) starts[os++] = r;
-      else ends[oe++] = r;
-    }
-    s = n;
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= ntiles * M) return;
+  const int col = (int)(g % M);
+  const long long tile = g / M;
+  int s = state_in[g];
+  unsigned long long os = off_s[g], oe = off_e[g];
+  for (int j = 0; j < kTileWords; ++j) {
+    const long long w = tile * kTileWords + j;
+    unsigned long long p0, p1;
+    word_scan(f0[w * M + col], f1[w * M + col], p0, p1);
+    const unsigned long long S = s ? p1 : p0, P = (S << 1) | (unsigned long long)s;
+    unsigned long long up = S & ~P, down = ~S & P;
+    while (up) { starts[os++] = w * 64 + (__ffsll((long long)up) - 1); up &= up - 1; }
+    while (down) { ends[oe++] = w * 64 + (__ffsll((long long)down) - 1); down &= down - 1; }
+    s = (int)(S >> 63);
   }
 }
 
@@ -470,11 +539,73 @@ __global__ void pdw_rebase_kernel(int M, long long ntiles, unsigned long long* o
 }
 
 // ---------------------------------------------------------------------------------
+// sample sources: where a (sample index, channel) pair finds its complex value
+
+struct ChanSrc {  // F x M channelizer output, frame-major complex64
+  const float2* y;
+  int M;
+  __device__ __forceinline__ double mag(long long i, int col) const { return mag_of(y[i * M + col]); }
+  __device__ __forceinline__ double phase(long long i, int col) const { return phase_deg(y[i * M + col]); }
+  __device__ __forceinline__ bool saturated(long long i, int col) const {
+    const float2 v = y[i * M + col];
+    return (fabs((double)v.x) >= 0.9999) || (fabs((double)v.y) >= 0.9999);
+  }
+};
+
+// the raw recorder stream (create_pdws.m:30-33): x = (I + jQ) / 2^(bit_width-1), one column.
+// |x|^2 orders like I^2 + Q^2, which is an exact integer for the integer formats.
+template <int FMT>
+struct RawSrc {
+  const void* p;
+  double inv_scale;  // 2^-(bit_width-1); 1 for cf32
+  __device__ __forceinline__ void reim(long long i, double& re, double& im) const {
+    if constexpr (FMT == PFB_FMT_INT8_IQ) {
+      const char2 v = static_cast<const char2*>(p)[i];
+      re = (double)v.x * inv_scale; im = (double)v.y * inv_scale;
+    } else if constexpr (FMT == PFB_FMT_INT16_IQ) {
+      const short2 v = static_cast<const short2*>(p)[i];
+      re = (double)v.x * inv_scale; im = (double)v.y * inv_scale;
+    } else {
+      const float2 v = static_cast<const float2*>(p)[i];
+      re = (double)v.x; im = (double)v.y;
+    }
+  }
+  // order-preserving key of |x_i|^2 and the magnitude it stands for
+  __device__ __forceinline__ unsigned long long key(long long i) const {
+    if constexpr (FMT == PFB_FMT_INT8_IQ) {
+      const char2 v = static_cast<const char2*>(p)[i];
+      return (unsigned long long)((int)v.x * (int)v.x + (int)v.y * (int)v.y);
+    } else if constexpr (FMT == PFB_FMT_INT16_IQ) {
+      const short2 v = static_cast<const short2*>(p)[i];
+      return (unsigned long long)((long long)v.x * v.x + (long long)v.y * v.y);
+    } else {
+      return dkey(mag2_of(static_cast<const float2*>(p)[i]));
+    }
+  }
+  __device__ __forceinline__ double key_mag(unsigned long long k) const {
+    if constexpr (FMT == PFB_FMT_CF32) return sqrt(dkey_inv(k));
+    else return sqrt((double)k) * inv_scale;
+  }
+  __device__ __forceinline__ double mag(long long i, int) const { return key_mag(key(i)); }
+  __device__ __forceinline__ double phase(long long i, int) const {
+    double re, im;
+    reim(i, re, im);
+    return atan2(im, re) * kRadToDeg;
+  }
+  __device__ __forceinline__ bool saturated(long long i, int) const {
+    double re, im;
+    reim(i, re, im);
+    return (fabs(re) >= 0.9999) || (fabs(im) >= 0.9999);
+  }
+};
+
+// ---------------------------------------------------------------------------------
 // per pulse
 
-__global__ void __launch_bounds__(256) pdw_pulse_kernel(const float2* y, int M, const long long* starts,
-                                                        const long long* ends, const unsigned long long* base_s,
-                                                        const unsigned long long* base_e, const double* nf, const double* bin_freqs, double fs, double fc,
+template <class Src>
+__global__ void __launch_bounds__(256) pdw_pulse_kernel(Src src, int M, const long long* starts, const long long* ends,
+                                                        const unsigned long long* base_s, const unsigned long long* base_e,
+                                                        const double* nf, const double* bin_freqs, double fs, double fc,
                                                         double t0, unsigned flags, pfb_pdw* out, unsigned long long capacity) {
   __shared__ unsigned hist[256];
   __shared__ unsigned long long pick[2];
@@ -486,8 +617,8 @@ __global__ void __launch_bounds__(256) pdw_pulse_kernel(const float2* y, int M, 
   // channel of this pulse: base_e is the exclusive prefix of tot_e over channels
   int lo = 0, hi = M - 1;
   while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (base_e[mid] <= pid) lo = mid; else hi = mid - 1;
+    const int mid_c = (lo + hi + 1) >> 1;
+    if (base_e[mid_c] <= pid) lo = mid_c; else hi = mid_c - 1;
   }
   // (the largest channel whose base <= pid is the pulse's channel: every later base is > pid)
   const int b = lo;
@@ -498,28 +629,26 @@ __global__ void __launch_bounds__(256) pdw_pulse_kernel(const float2* y, int M, 
   if (threadIdx.x == 0) sat_flag = 0;
   __syncthreads();
 
-  // :130-132 saturation: samples strictly inside the pulse (the edge samples take the other branches)
+  // :130-132 / create_pdws.m:100-102 saturation: samples strictly inside the pulse (the edge samples take
+  // the other branches)
   int sat = 0;
-  for (long long i = toa + 1 + threadIdx.x; i < jj; i += blockDim.x) {
-    const float2 v = y[i * M + b];
-    sat |= (fabs((double)v.x) >= 0.9999) || (fabs((double)v.y) >= 0.9999);
-  }
+  for (long long i = toa + 1 + threadIdx.x; i < jj; i += blockDim.x) sat |= src.saturated(i, b);
   if (sat) atomicOr(&sat_flag, 1);
 
-  // :101 amplitude = median magnitude over toa..jj
+  // :101 / :70 amplitude = median magnitude over toa..jj
   double amp;
   if (n <= kPulseCache) {
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) cache[i] = mag_of(y[(toa + i) * M + b]);
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) cache[i] = src.mag(toa + i, b);
     __syncthreads();
     amp = cached_median(cache, (int)n, mid);
   } else {
-    amp = block_median([&](long long i) { return mag_of(y[(toa + i) * M + b]); }, n, hist, pick);
+    amp = block_median([&](long long i) { return src.mag(toa + i, b); }, n, hist, pick);
   }
   __syncthreads();
 
-  // :114-117 median of the wrapped phase steps (degrees)
+  // :114-117 / :83-86 median of the wrapped phase steps (degrees)
   auto dphi = [&](long long i) {
-    double d = phase_deg(y[(toa + i + 1) * M + pcol]) - phase_deg(y[(toa + i) * M + pcol]);
+    double d = src.phase(toa + i + 1, pcol) - src.phase(toa + i, pcol);
     if (d < -180.0) d += 360.0;
     if (d > 180.0) d -= 360.0;
     return d;
@@ -535,16 +664,80 @@ __global__ void __launch_bounds__(256) pdw_pulse_kernel(const float2* y, int M, 
   __syncthreads();
   if (threadIdx.x == 0) {
     pfb_pdw o;
-    o.toa = ((double)(toa + 1) / fs) + t0;            // :98 (1-based index)
-    o.snr = 10.0 * log10(amp / nf[b]);                // :105
-    o.pw = (double)(jj - toa) / fs;                   // :110
-    // :80 indexes the UNSHIFTED centre-frequency list with the shifted column
-    const double fbin = (flags & PFB_PDW_MATLAB_QUIRKS) ? bin_freqs[b] : bin_freqs[(b + (M + 1) / 2) % M];
-    o.freq = (fc + fbin) + (fs / (360.0 / med));      // :122
+    o.toa = ((double)(toa + 1) / fs) + t0;            // :98 / :67 (1-based index)
+    o.snr = 10.0 * log10(amp / nf[b]);                // :105 / :74
+    o.pw = (double)(jj - toa) / fs;                   // :110 / :79
+    // :80 indexes the UNSHIFTED centre-frequency list with the shifted column; the raw script has no bins
+    const double fbin = !bin_freqs ? 0.0
+                        : (flags & PFB_PDW_MATLAB_QUIRKS) ? bin_freqs[b] : bin_freqs[(b + (M + 1) / 2) % M];
+    o.freq = (fc + fbin) + (fs / (360.0 / med));      // :122 / :91
     o.sat = sat_flag;
     o.bin = b;
+    o.mag = amp;
     out[pid] = o;
   }
+}
+
+// ---------------------------------------------------------------------------------
+// raw stream: noise floor and masks, time-parallel (one column, so lanes are consecutive samples)
+
+constexpr int kRawBits = 11, kRawBins = 1 << kRawBits;
+
+// one digit pass of the radix select of the stream's median |x|^2 key: digit = (key >> shift) & (bins-1)
+// among keys whose bits above the digit equal `prefix`
+template <class Src>
+__global__ void __launch_bounds__(256) pdw_raw_hist_kernel(Src src, long long n, int shift, unsigned bins_mask,
+                                                           unsigned long long prefix, unsigned long long prefix_mask,
+                                                           unsigned* hist) {
+  __shared__ unsigned h[kRawBins];
+  for (int i = threadIdx.x; i < kRawBins; i += 256) h[i] = 0u;
+  __syncthreads();
+  const long long step = (long long)gridDim.x * 256;
+  for (long long i0 = (long long)blockIdx.x * 256; i0 < n; i0 += step) {
+    const long long i = i0 + threadIdx.x;
+    const unsigned long long k = (i < n) ? src.key(i) : 0ull;
+    hist_add(h, (unsigned)(k >> shift) & bins_mask, (i < n) && ((k & prefix_mask) == prefix));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kRawBins; i += 256)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// number of keys below `pivot` and the largest of them (the lower middle value of an even-length median)
+template <class Src>
+__global__ void __launch_bounds__(256) pdw_raw_below_kernel(Src src, long long n, unsigned long long pivot,
+                                                            unsigned long long* below, unsigned long long* max_below) {
+  unsigned long long nb = 0ull, best = 0ull;
+  bool any = false;
+  const long long step = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += step) {
+    const unsigned long long k = src.key(i);
+    if (k < pivot) { ++nb; best = (any && best > k) ? best : k; any = true; }
+  }
+  if (any) { atomicAdd(below, nb); atomicMax(max_below, best); }
+}
+
+// comparison masks of the raw stream.  A wave covers 64 consecutive words: in step i every lane compares
+// sample 64 * (w0 + i) + lane (one coalesced load), the wave votes, lane i keeps the word.
+template <class Src>
+__global__ void __launch_bounds__(256) pdw_raw_mask_kernel(Src src, long long n, double lead, double trail,
+                                                           unsigned long long* f0, unsigned long long* f1, long long words) {
+  const int lane = threadIdx.x & 63;
+  const long long w0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (w0 >= words) return;
+  unsigned long long a = 0ull, b = 0ull;
+  for (int i = 0; i < 64; ++i) {
+    const long long sidx = (w0 + i) * 64 + lane;
+    bool ge = false, gt = true;  // past the end: identity
+    if (sidx < n) {
+      const double m = src.mag(sidx, 0);
+      ge = m >= lead;
+      gt = m > trail;
+    }
+    const unsigned long long wa = __ballot(ge), wb = __ballot(gt);
+    if (lane == i) { a = wa; b = wb; }
+  }
+  if (w0 + lane < words) { f0[w0 + lane] = a; f1[w0 + lane] = b; }
 }
 
 // ---------------------------------------------------------------------------------
@@ -618,6 +811,117 @@ extern "C" int pfb_pdw_release_workspace(int32_t device_id) {
   return PFB_OK;
 }
 
+// host twin of dkey_inv (the raw cf32 noise floor is finished on the host)
+static double dkey_inv_host(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  double d;
+  std::memcpy(&d, &b, sizeof d);
+  return d;
+}
+
+namespace {
+
+// device buffers of the edge stage, all inside arena 0
+struct EdgeStage {
+  unsigned long long *f0, *f1, *off_s, *off_e, *tot, *base;
+  unsigned char *fn, *state;
+  ushort4* cnt;
+  double *nf, *binf;  // binf == nullptr: no per-channel centre frequencies (raw stream)
+};
+
+size_t edge_stage_bytes(long long words, long long ntiles, uint32_t M) {
+  const size_t wm = (size_t)words * M, tm = (size_t)ntiles * M;
+  return 2 * padded(wm * sizeof(unsigned long long)) + 2 * padded(tm * sizeof(unsigned long long)) +
+         2 * padded(2 * (size_t)M * sizeof(unsigned long long)) + 2 * padded(tm) + padded(tm * sizeof(ushort4)) +
+         2 * padded(M * sizeof(double));
+}
+
+EdgeStage take_edge_stage(Arena& ws, long long words, long long ntiles, uint32_t M, bool with_binf) {
+  const size_t wm = (size_t)words * M, tm = (size_t)ntiles * M;
+  EdgeStage e{};
+  e.f0 = take<unsigned long long>(ws, wm);
+  e.f1 = take<unsigned long long>(ws, wm);
+  e.off_s = take<unsigned long long>(ws, tm);
+  e.off_e = take<unsigned long long>(ws, tm);
+  e.tot = take<unsigned long long>(ws, 2 * (size_t)M);
+  e.base = take<unsigned long long>(ws, 2 * (size_t)M);
+  e.fn = take<unsigned char>(ws, tm);
+  e.state = take<unsigned char>(ws, tm);
+  e.cnt = take<ushort4>(ws, tm);
+  e.nf = take<double>(ws, M);
+  double* binf = take<double>(ws, M);
+  e.binf = with_binf ? binf : nullptr;
+  return e;
+}
+
+// masks (e.f0, e.f1) and noise floors (e.nf) are on the device: tile summaries, scan, edge lists, one
+// workgroup per pulse, PDWs back to the host.
+template <class Src>
+int edges_and_pulses(Src src, int Mi, long long ntiles, const EdgeStage& e, Arena& ws2, double fs, double fc, double t0,
+                     unsigned flags, pfb_pdw* out, uint64_t capacity, uint64_t* count, hipStream_t st) {
+  int rc = PFB_OK;
+  const uint32_t M = (uint32_t)Mi;
+  const size_t tm = (size_t)ntiles * M;
+  std::vector<unsigned long long> h_tot(2 * (size_t)M), h_base(2 * (size_t)M);
+  unsigned long long total_s = 0, total_e = 0;
+  const unsigned tblocks = (unsigned)((tm + 255) / 256);
+  hipLaunchKernelGGL(pdw_tilefn_kernel, dim3(tblocks), dim3(256), 0, st, (const unsigned long long*)e.f0,
+                     (const unsigned long long*)e.f1, Mi, ntiles, e.fn, e.cnt);
+  hipLaunchKernelGGL(pdw_tilescan_kernel, dim3(Mi), dim3(64), 0, st, Mi, ntiles, (const unsigned char*)e.fn,
+                     (const ushort4*)e.cnt, e.state, e.off_s, e.off_e, e.tot, e.tot + M);
+  PDW_TRY(hipGetLastError());
+  PDW_TRY(hipMemcpyAsync(h_tot.data(), e.tot, 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  PDW_TRY(hipStreamSynchronize(st));
+  for (uint32_t b = 0; b < M; ++b) {  // channels outermost, like the reference's for bin = 1:M
+    h_base[b] = total_s; h_base[M + b] = total_e;
+    total_s += h_tot[b]; total_e += h_tot[M + b];
+  }
+  *count = total_e;  // a pulse still active at the end of the data produces no PDW (the trailing test never fires)
+  if (total_e > 0) {
+    const unsigned long long n_out = std::min<unsigned long long>(total_e, capacity);
+    PDW_TRY(arena_reserve(ws2, padded((size_t)total_s * sizeof(long long)) + padded((size_t)total_e * sizeof(long long)) +
+                                   padded((size_t)n_out * sizeof(pfb_pdw)) + kAlign));
+    long long* d_starts = take<long long>(ws2, (size_t)total_s);
+    long long* d_ends = take<long long>(ws2, (size_t)total_e);
+    pfb_pdw* d_out = take<pfb_pdw>(ws2, (size_t)n_out);
+    PDW_TRY(hipMemcpyAsync(e.base, h_base.data(), 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pdw_rebase_kernel, dim3(tblocks), dim3(256), 0, st, Mi, ntiles, e.off_s, e.off_e,
+                       (const unsigned long long*)e.base, (const unsigned long long*)(e.base + M));
+    hipLaunchKernelGGL(pdw_edges_kernel, dim3(tblocks), dim3(256), 0, st, (const unsigned long long*)e.f0,
+                       (const unsigned long long*)e.f1, Mi, ntiles, (const unsigned char*)e.state,
+                       (const unsigned long long*)e.off_s, (const unsigned long long*)e.off_e, d_starts, d_ends);
+    if (n_out > 0) {
+      hipLaunchKernelGGL(pdw_pulse_kernel<Src>, dim3((unsigned)n_out), dim3(256), 0, st, src, Mi, (const long long*)d_starts,
+                         (const long long*)d_ends, (const unsigned long long*)e.base, (const unsigned long long*)(e.base + M),
+                         (const double*)e.nf, (const double*)e.binf, fs, fc, t0, flags, d_out, n_out);
+      PDW_TRY(hipGetLastError());
+      PDW_TRY(hipMemcpyAsync(out, d_out, (size_t)n_out * sizeof(pfb_pdw), hipMemcpyDeviceToHost, st));
+    }
+    PDW_TRY(hipStreamSynchronize(st));
+  }
+done:
+  return rc;
+}
+
+// RAII: select the device for the call, restore on exit
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  int enter(int32_t device_id, int ndev) {
+    (void)hipGetDevice(&prev);
+    if (device_id >= 0 && device_id != prev) {
+      if (device_id >= ndev || hipSetDevice(device_id) != hipSuccess) return PFB_ERR_BAD_ARG;
+      switched = true;
+    }
+    return PFB_OK;
+  }
+  ~DeviceScope() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+}  // namespace
+
 extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, uint32_t decimation, double fs_in,
                                double fc, double sample_start_time, double snr_threshold_db, uint32_t flags,
                                pfb_pdw* out, uint64_t capacity, uint64_t* count, double* noise_floor_out, uint32_t mem,
@@ -629,11 +933,8 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
     (void)hipGetLastError();
     return PFB_ERR_NO_DEVICE;
   }
-  int prev_dev = -1;
-  (void)hipGetDevice(&prev_dev);
-  if (device_id >= 0 && device_id != prev_dev) {
-    if (device_id >= ndev || hipSetDevice(device_id) != hipSuccess) return PFB_ERR_BAD_ARG;
-  }
+  DeviceScope scope;
+  if (scope.enter(device_id, ndev) != PFB_OK) return PFB_ERR_BAD_ARG;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= kMaxDevices) return PFB_ERR_BAD_ARG;
@@ -645,7 +946,7 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
   const long long F = (long long)frames;
   const int Mi = (int)M;
   const long long ntiles = (F + kTile - 1) / kTile;
-  const size_t tm = (size_t)ntiles * M;
+  const long long words = ntiles * kTileWords;  // whole tiles; the tail is identity-padded
   const int cgroups = (Mi + 63) / 64;
   const double fs = fs_in / (double)decimation;  // :62
   int rc = PFB_OK;
@@ -660,16 +961,12 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
 
   const float2* d_y = nullptr;
   unsigned *d_hist, *d_bucket, *d_cand_n, *d_flags;
-  unsigned long long *d_prefix, *d_prefix_hi, *d_rank, *d_below, *d_maxbelow, *d_off_s, *d_off_e, *d_tot, *d_base;
-  double *d_cand, *d_nf, *d_thr, *d_binf;
-  unsigned char *d_fn, *d_state;
-  ushort4* d_cnt;
-  long long *d_starts = nullptr, *d_ends = nullptr;
-  pfb_pdw* d_out = nullptr;
+  unsigned long long *d_prefix, *d_prefix_hi, *d_rank, *d_below, *d_maxbelow;
+  double *d_cand, *d_thr;
+  EdgeStage e{};
   std::vector<unsigned> h_bucket(M);
-  std::vector<unsigned long long> h_rank(M), h_tot(2 * (size_t)M), h_base(2 * (size_t)M);
+  std::vector<unsigned long long> h_rank(M);
   std::vector<double> h_nf(M), h_thr(M), h_binf(M);
-  unsigned long long total_s = 0, total_e = 0;
   unsigned h_flags = 0;
   bool have_nf = false;
   int passes = 0;
@@ -679,10 +976,10 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
   {
     size_t need = 0;
     if (mem == PFB_MEM_HOST) need += padded((size_t)F * M * sizeof(float2));
-    need += padded((size_t)M * 256 * sizeof(unsigned)) + 3 * padded(M * sizeof(unsigned)) + padded(sizeof(unsigned));
-    need += 5 * padded(M * sizeof(unsigned long long)) + 2 * padded(2 * (size_t)M * sizeof(unsigned long long));
-    need += padded(cand_elems * sizeof(double)) + 3 * padded(M * sizeof(double));
-    need += 2 * padded(tm) + padded(tm * sizeof(ushort4)) + 2 * padded(tm * sizeof(unsigned long long));
+    need += padded((size_t)M * 256 * sizeof(unsigned)) + 2 * padded(M * sizeof(unsigned)) + padded(sizeof(unsigned));
+    need += 5 * padded(M * sizeof(unsigned long long));
+    need += padded(cand_elems * sizeof(double)) + padded(M * sizeof(double));
+    need += edge_stage_bytes(words, ntiles, M);
     PDW_TRY(arena_reserve(ws, need));
   }
   if (mem == PFB_MEM_HOST) {
@@ -701,18 +998,9 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
   d_rank = take<unsigned long long>(ws, M);
   d_below = take<unsigned long long>(ws, M);
   d_maxbelow = take<unsigned long long>(ws, M);
-  d_tot = take<unsigned long long>(ws, 2 * (size_t)M);
-  d_base = take<unsigned long long>(ws, 2 * (size_t)M);
   d_cand = take<double>(ws, cand_elems);
-  d_nf = take<double>(ws, M);
   d_thr = take<double>(ws, M);
-  d_binf = take<double>(ws, M);
-  d_fn = take<unsigned char>(ws, tm);
-  d_state = take<unsigned char>(ws, tm);
-  d_cnt = take<ushort4>(ws, tm);
-  d_off_s = take<unsigned long long>(ws, tm);
-  d_off_e = take<unsigned long long>(ws, tm);
-  (void)take<unsigned>(ws, M);  // spare
+  e = take_edge_stage(ws, words, ntiles, M, true);
 
   PDW_TRY(hipMemsetAsync(d_hist, 0, (size_t)M * 256 * sizeof(unsigned), st));
 
@@ -739,10 +1027,10 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
     hipLaunchKernelGGL(pdw_bracket_kernel, dim3(cgroups, (unsigned)((F + kBracketRows - 1) / kBracketRows)), dim3(256), 0, st,
                        d_y, F, Mi, d_prefix, d_prefix_hi, d_cand, cap, d_cand_n, d_below, d_maxbelow, d_flags);
     hipLaunchKernelGGL(pdw_bracket_finish_kernel, dim3(Mi), dim3(1024), 0, st, F, d_cand, cap, d_cand_n, d_below, d_maxbelow,
-                       d_nf, d_flags);
+                       e.nf, d_flags);
     PDW_TRY(hipGetLastError());
     PDW_TRY(hipMemcpyAsync(&h_flags, d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    PDW_TRY(hipMemcpyAsync(h_nf.data(), d_nf, M * sizeof(double), hipMemcpyDeviceToHost, st));
+    PDW_TRY(hipMemcpyAsync(h_nf.data(), e.nf, M * sizeof(double), hipMemcpyDeviceToHost, st));
     PDW_TRY(hipStreamSynchronize(st));
     have_nf = (h_flags == 0);
   }
@@ -768,9 +1056,9 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
     hipLaunchKernelGGL(pdw_collect_kernel, dim3(cgroups, row_blocks), dim3(256), 0, st, d_y, F, Mi, passes, d_prefix, d_cand,
                        d_cand_n, d_maxbelow);
     hipLaunchKernelGGL(pdw_median_finish_kernel, dim3(Mi), dim3(256), 0, st, F, passes, d_cand, d_cand_n, d_prefix, d_rank,
-                       d_maxbelow, d_nf);
+                       d_maxbelow, e.nf);
     PDW_TRY(hipGetLastError());
-    PDW_TRY(hipMemcpyAsync(h_nf.data(), d_nf, M * sizeof(double), hipMemcpyDeviceToHost, st));
+    PDW_TRY(hipMemcpyAsync(h_nf.data(), e.nf, M * sizeof(double), hipMemcpyDeviceToHost, st));
     PDW_TRY(hipStreamSynchronize(st));
   }
   {
@@ -780,46 +1068,148 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
     if (noise_floor_out) std::memcpy(noise_floor_out, h_nf.data(), M * sizeof(double));
   }
   PDW_TRY(hipMemcpyAsync(d_thr, h_thr.data(), M * sizeof(double), hipMemcpyHostToDevice, st));
-  PDW_TRY(hipMemcpyAsync(d_binf, h_binf.data(), M * sizeof(double), hipMemcpyHostToDevice, st));
+  PDW_TRY(hipMemcpyAsync(e.binf, h_binf.data(), M * sizeof(double), hipMemcpyHostToDevice, st));
 
-  // ---- edges (:85-135)
-  {
-    const dim3 tgrid(cgroups, (unsigned)((ntiles + 3) / 4));
-    hipLaunchKernelGGL(pdw_tilefn_kernel, tgrid, dim3(256), 0, st, d_y, F, Mi, d_thr, d_fn, d_cnt, ntiles);
-    hipLaunchKernelGGL(pdw_tilescan_kernel, dim3(Mi), dim3(64), 0, st, Mi, ntiles, d_fn, d_cnt, d_state, d_off_s, d_off_e, d_tot,
-                       d_tot + M);
-    PDW_TRY(hipGetLastError());
-    PDW_TRY(hipMemcpyAsync(h_tot.data(), d_tot, 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    PDW_TRY(hipStreamSynchronize(st));
-    for (uint32_t b = 0; b < M; ++b) {  // channels outermost, like the reference's for bin = 1:M
-      h_base[b] = total_s; h_base[M + b] = total_e;
-      total_s += h_tot[b]; total_e += h_tot[M + b];
-    }
-    *count = total_e;  // a pulse still active at the end of the data produces no PDW (:94 never fires)
-    if (total_e > 0) {
-      const unsigned long long n_out = std::min<unsigned long long>(total_e, capacity);
-      PDW_TRY(arena_reserve(ws2, padded((size_t)total_s * sizeof(long long)) + padded((size_t)total_e * sizeof(long long)) +
-                                     padded((size_t)n_out * sizeof(pfb_pdw)) + kAlign));
-      d_starts = take<long long>(ws2, (size_t)total_s);
-      d_ends = take<long long>(ws2, (size_t)total_e);
-      d_out = take<pfb_pdw>(ws2, (size_t)n_out);
-      PDW_TRY(hipMemcpyAsync(d_base, h_base.data(), 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(pdw_rebase_kernel, dim3((unsigned)((tm + 255) / 256)), dim3(256), 0, st, Mi, ntiles, d_off_s, d_off_e,
-                         d_base, d_base + M);
-      hipLaunchKernelGGL(pdw_edges_kernel, tgrid, dim3(256), 0, st, d_y, F, Mi, d_thr, d_state, ntiles,
-                         (const unsigned long long*)d_off_s, (const unsigned long long*)d_off_e, d_starts, d_ends);
-      if (n_out > 0) {
-        hipLaunchKernelGGL(pdw_pulse_kernel, dim3((unsigned)n_out), dim3(256), 0, st, d_y, Mi, d_starts, d_ends, d_base,
-                           d_base + M, d_nf, d_binf, fs, fc, sample_start_time, flags, d_out, n_out);
-        PDW_TRY(hipGetLastError());
-        PDW_TRY(hipMemcpyAsync(out, d_out, (size_t)n_out * sizeof(pfb_pdw), hipMemcpyDeviceToHost, st));
-      }
-      PDW_TRY(hipStreamSynchronize(st));
-    }
-  }
+  // ---- edges (:85-135) and pulses (:98-132)
+  hipLaunchKernelGGL(pdw_mask_kernel, dim3(cgroups, (unsigned)((words + 3) / 4)), dim3(256), 0, st, d_y, F, Mi,
+                     (const double*)d_thr, e.f0, e.f1, words);
+  PDW_TRY(hipGetLastError());
+  rc = edges_and_pulses(ChanSrc{d_y, Mi}, Mi, ntiles, e, ws2, fs, fc, sample_start_time, flags, out, capacity, count, st);
 
 done:
   (void)hipStreamSynchronize(st);
-  if (device_id >= 0 && device_id != prev_dev && prev_dev >= 0) (void)hipSetDevice(prev_dev);
+  return rc;
+}
+
+// ---- raw stream (matlab/create_pdws.m:30-105) -------------------------------------------------------
+
+namespace {
+
+template <int FMT>
+int extract_raw(const void* d_iq, long long n, double inv_scale, double fs, double fc, double t0, double lead_db,
+                double trail_db, pfb_pdw* out, uint64_t capacity, uint64_t* count, double* noise_floor_out, Arena& ws,
+                Arena& ws2, const EdgeStage& e, unsigned* d_hist, unsigned long long* d_pair, long long words,
+                long long ntiles, hipStream_t st) {
+  int rc = PFB_OK;
+  const RawSrc<FMT> src{d_iq, inv_scale};
+  (void)ws;
+  // ---- noise floor (:44): radix select of rank n/2 on the |x|^2 keys, 11-bit digits
+  struct Pass { int shift, bits; };
+  static const Pass kIntPasses[] = {{22, 11}, {11, 11}, {0, 11}};                            // keys < 2^33
+  static const Pass kF32Passes[] = {{53, 11}, {42, 11}, {31, 11}, {20, 11}, {9, 11}, {0, 9}};  // 64-bit double keys
+  const Pass* pass = (FMT == PFB_FMT_CF32) ? kF32Passes : kIntPasses;
+  const int npass = (FMT == PFB_FMT_CF32) ? 6 : 3;
+  const unsigned grid = (unsigned)std::min<long long>(4096, std::max<long long>(1, (n + 2047) / 2048));
+  std::vector<unsigned> h_hist(kRawBins);
+  unsigned long long prefix = 0ull, rank = (unsigned long long)(n / 2), h_pair[2] = {0ull, 0ull};
+  double nf = 0.0, lead = 0.0, trail = 0.0;
+  for (int ps = 0; ps < npass; ++ps) {
+    const int top = pass[ps].shift + pass[ps].bits;
+    const unsigned long long pmask = top >= 64 ? 0ull : (~0ull << top);
+    PDW_TRY(hipMemsetAsync(d_hist, 0, kRawBins * sizeof(unsigned), st));
+    hipLaunchKernelGGL(pdw_raw_hist_kernel<RawSrc<FMT>>, dim3(grid), dim3(256), 0, st, src, n, pass[ps].shift,
+                       (1u << pass[ps].bits) - 1u, prefix, pmask, d_hist);
+    PDW_TRY(hipGetLastError());
+    PDW_TRY(hipMemcpyAsync(h_hist.data(), d_hist, kRawBins * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    PDW_TRY(hipStreamSynchronize(st));
+    unsigned long long cum = 0;
+    int d = 0;
+    const int last = (1 << pass[ps].bits) - 1;
+    for (; d < last; ++d) {
+      if (cum + h_hist[d] > rank) break;
+      cum += h_hist[d];
+    }
+    prefix |= (unsigned long long)d << pass[ps].shift;
+    rank -= cum;
+  }
+  {
+    auto key_mag = [&](unsigned long long k) {
+      return (FMT == PFB_FMT_CF32) ? std::sqrt(dkey_inv_host(k)) : std::sqrt((double)k) * inv_scale;
+    };
+    unsigned long long v0 = prefix;
+    if ((n & 1) == 0) {  // even count: the lower middle value is the largest key below, unless the pivot repeats
+      PDW_TRY(hipMemsetAsync(d_pair, 0, 2 * sizeof(unsigned long long), st));
+      hipLaunchKernelGGL(pdw_raw_below_kernel<RawSrc<FMT>>, dim3(grid), dim3(256), 0, st, src, n, prefix, d_pair, d_pair + 1);
+      PDW_TRY(hipGetLastError());
+      PDW_TRY(hipMemcpyAsync(h_pair, d_pair, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      PDW_TRY(hipStreamSynchronize(st));
+      if (h_pair[0] == (unsigned long long)(n / 2)) v0 = h_pair[1];
+    }
+    nf = (n & 1) ? key_mag(prefix) : 0.5 * (key_mag(v0) + key_mag(prefix));
+    lead = nf * std::pow(10.0, lead_db / 10.0);    // :45-46
+    trail = nf * std::pow(10.0, trail_db / 10.0);  // :47
+    if (noise_floor_out) *noise_floor_out = nf;
+  }
+  PDW_TRY(hipMemcpyAsync(e.nf, &nf, sizeof(double), hipMemcpyHostToDevice, st));
+  PDW_TRY(hipStreamSynchronize(st));  // nf lives on this stack frame
+  // ---- edges (:54-105) and pulses
+  hipLaunchKernelGGL(pdw_raw_mask_kernel<RawSrc<FMT>>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, src, n, lead,
+                     trail, e.f0, e.f1, words);
+  PDW_TRY(hipGetLastError());
+  rc = edges_and_pulses(src, 1, ntiles, e, ws2, fs, fc, t0, 0u, out, capacity, count, st);
+done:
+  return rc;
+}
+
+}  // namespace
+
+extern "C" int pfb_pdw_extract_raw(const void* iq, uint64_t num_samples, uint32_t sample_format, uint32_t bit_width,
+                                   double fs, double fc, double sample_start_time, double snr_threshold_db,
+                                   double trailing_threshold_db, pfb_pdw* out, uint64_t capacity, uint64_t* count,
+                                   double* noise_floor_out, uint32_t mem, int32_t device_id, void* hip_stream) {
+  if (!iq || !count || num_samples < 2 || sample_format > PFB_FMT_CF32 || mem > PFB_MEM_DEVICE || (capacity && !out))
+    return PFB_ERR_BAD_ARG;
+  if (sample_format != PFB_FMT_CF32 && (bit_width < 1 || bit_width > 16)) return PFB_ERR_BAD_ARG;
+  if (!(trailing_threshold_db <= snr_threshold_db)) return PFB_ERR_BAD_ARG;  // the masks assume lead >= trail
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return PFB_ERR_NO_DEVICE;
+  }
+  DeviceScope scope;
+  if (scope.enter(device_id, ndev) != PFB_OK) return PFB_ERR_BAD_ARG;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= kMaxDevices) return PFB_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  Arena& ws = g_ws[dev][0];
+  Arena& ws2 = g_ws[dev][1];
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const long long n = (long long)num_samples;
+  const long long ntiles = (n + kTile - 1) / kTile;
+  const long long words = ntiles * kTileWords;
+  const size_t bps = sample_format == PFB_FMT_INT8_IQ ? 2 : sample_format == PFB_FMT_INT16_IQ ? 4 : 8;
+  const double inv_scale = sample_format == PFB_FMT_CF32 ? 1.0 : std::ldexp(1.0, -((int)bit_width - 1));
+  int rc = PFB_OK;
+  const void* d_iq = iq;
+  unsigned* d_hist;
+  unsigned long long* d_pair;
+  EdgeStage e{};
+  PDW_TRY(arena_reserve(ws, (mem == PFB_MEM_HOST ? padded((size_t)n * bps) : 0) + padded(kRawBins * sizeof(unsigned)) +
+                                padded(2 * sizeof(unsigned long long)) + edge_stage_bytes(words, ntiles, 1)));
+  if (mem == PFB_MEM_HOST) {
+    char* own = take<char>(ws, (size_t)n * bps);
+    PDW_TRY(hipMemcpyAsync(own, iq, (size_t)n * bps, hipMemcpyHostToDevice, st));
+    d_iq = own;
+  }
+  d_hist = take<unsigned>(ws, kRawBins);
+  d_pair = take<unsigned long long>(ws, 2);
+  e = take_edge_stage(ws, words, ntiles, 1, false);
+  switch (sample_format) {
+    case PFB_FMT_INT8_IQ:
+      rc = extract_raw<PFB_FMT_INT8_IQ>(d_iq, n, inv_scale, fs, fc, sample_start_time, snr_threshold_db, trailing_threshold_db,
+                                        out, capacity, count, noise_floor_out, ws, ws2, e, d_hist, d_pair, words, ntiles, st);
+      break;
+    case PFB_FMT_INT16_IQ:
+      rc = extract_raw<PFB_FMT_INT16_IQ>(d_iq, n, inv_scale, fs, fc, sample_start_time, snr_threshold_db, trailing_threshold_db,
+                                         out, capacity, count, noise_floor_out, ws, ws2, e, d_hist, d_pair, words, ntiles, st);
+      break;
+    default:
+      rc = extract_raw<PFB_FMT_CF32>(d_iq, n, inv_scale, fs, fc, sample_start_time, snr_threshold_db, trailing_threshold_db,
+                                     out, capacity, count, noise_floor_out, ws, ws2, e, d_hist, d_pair, words, ntiles, st);
+      break;
+  }
+done:
+  (void)hipStreamSynchronize(st);
   return rc;
 }

@@ -1,6 +1,8 @@
-"""Channelized PDW extraction (the second half of matlab/create_pdws_channelized.m, lines 64-143)
-over the C ABI's pfb_pdw_extract.  Returns the same fields the script accumulates in its ``pdw``
-struct (:16-20,124-128): toa, freq, pw, snr, sat -- plus the column each pulse was found in."""
+"""PDW extraction over the C ABI: the channelized one (the second half of
+matlab/create_pdws_channelized.m, lines 64-143, pfb_pdw_extract) and the raw-stream one
+(matlab/create_pdws.m:30-105, pfb_pdw_extract_raw).  Both return the fields the scripts accumulate in
+their ``pdw`` struct -- toa, freq, pw, snr, sat, and mag (create_pdws.m:96) -- plus the column each pulse
+was found in."""
 from __future__ import annotations
 
 import ctypes as C
@@ -9,7 +11,8 @@ import numpy as np
 
 from . import _lib as L
 
-PDW_DTYPE = np.dtype([("toa", "f8"), ("freq", "f8"), ("pw", "f8"), ("snr", "f8"), ("sat", "i4"), ("bin", "i4")])
+PDW_DTYPE = np.dtype([("toa", "f8"), ("freq", "f8"), ("pw", "f8"), ("snr", "f8"), ("sat", "i4"), ("bin", "i4"),
+                      ("mag", "f8")])
 
 
 def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decimation: int | None = None,
@@ -49,3 +52,48 @@ def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decima
     if n > capacity:
         raise OverflowError(f"{n} pulses found, capacity {capacity}")
     return (out[:n], nf) if return_noise_floor else out[:n]
+
+
+def extract_pdws_raw(iq, fs: float, fc: float, sample_start_time: float, *, bit_width: int = 12,
+                     snr_threshold_db: float = 18.0, trailing_threshold_db: float = 3.0, capacity: int = 1 << 20,
+                     return_noise_floor: bool = False, device: int = -1):
+    """create_pdws.m on the recorder stream: iq is (n, 2) int8 / int16 (I, Q columns; bit_width as in the
+    record header) or (n,) complex64 -- a numpy array or a torch CUDA tensor (used in place).  Defaults are
+    the script's thresholds (18 dB leading, 3 dB trailing)."""
+    lib = L.load()
+    is_torch = type(iq).__module__.startswith("torch")
+    if is_torch and iq.is_cuda:
+        import torch
+        if not iq.is_contiguous():
+            raise ValueError("need a contiguous tensor")
+        fmt = {torch.int8: L.PFB_FMT_INT8_IQ, torch.int16: L.PFB_FMT_INT16_IQ, torch.complex64: L.PFB_FMT_CF32}[iq.dtype]
+        n = int(iq.shape[0])
+        ptr, mem, keep = C.c_void_p(iq.data_ptr()), L.PFB_MEM_DEVICE, iq
+        stream = C.c_void_p(torch.cuda.current_stream(iq.device).cuda_stream)
+        device = iq.device.index
+    else:
+        a = np.ascontiguousarray(np.asarray(iq))
+        if a.dtype == np.complex64:
+            fmt = L.PFB_FMT_CF32
+        elif a.dtype in (np.int8, np.int16) and a.ndim == 2 and a.shape[1] == 2:
+            fmt = L.PFB_FMT_INT8_IQ if a.dtype == np.int8 else L.PFB_FMT_INT16_IQ
+        else:
+            raise ValueError("iq must be (n, 2) int8/int16 or (n,) complex64")
+        n = int(a.shape[0])
+        ptr, mem, keep, stream = C.c_void_p(a.ctypes.data), L.PFB_MEM_HOST, a, C.c_void_p(0)
+    out = np.zeros(capacity, dtype=PDW_DTYPE)
+    assert out.dtype.itemsize == C.sizeof(L.PfbPdw)
+    nf = C.c_double(0.0)
+    count = C.c_uint64(0)
+    rc = lib.pfb_pdw_extract_raw(ptr, n, fmt, int(bit_width), float(fs), float(fc), float(sample_start_time),
+                                 float(snr_threshold_db), float(trailing_threshold_db),
+                                 out.ctypes.data_as(C.POINTER(L.PfbPdw)), capacity, C.byref(count), C.byref(nf), mem,
+                                 int(device), stream)
+    del keep
+    if rc != L.PFB_OK:
+        detail = lib.pfb_pdw_last_error_detail().decode()
+        raise L.PfbError(rc, "pfb_pdw_extract_raw" + (f" [{detail}]" if detail else ""))
+    k = int(count.value)
+    if k > capacity:
+        raise OverflowError(f"{k} pulses found, capacity {capacity}")
+    return (out[:k], nf.value) if return_noise_floor else out[:k]

@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from sdr_channelizer_amd import Channelizer, synth  # noqa: E402
-from sdr_channelizer_amd.pdw import extract_pdws  # noqa: E402
+from sdr_channelizer_amd.pdw import extract_pdws, extract_pdws_raw  # noqa: E402
 
 
 def compare(got, want, fs):
@@ -20,6 +20,7 @@ def compare(got, want, fs):
     assert np.allclose(got["pw"], w["pw"], rtol=1e-12, atol=0)
     assert np.allclose(got["snr"], w["snr"], rtol=1e-9, atol=1e-9, equal_nan=True)
     assert np.allclose(got["freq"], w["freq"], rtol=1e-9, atol=1e-6, equal_nan=True)
+    assert np.allclose(got["mag"], np.array([p["mag"] for p in want]), rtol=1e-12, atol=0)
 
 
 def synthetic_matrix(F=6000, M=16, seed=0):
@@ -122,3 +123,86 @@ def test_config5_end_to_end(oracle):
     # (the many short detections are the rectangular pulses' edge transients in the other channels)
     assert np.count_nonzero(np.abs(got["pw"] - 100e-6) < 15e-6) >= 60
     assert bool(torch.isfinite(torch.view_as_real(y)).all())
+
+
+# ---- raw stream (matlab/create_pdws.m) ------------------------------------------------------------------
+
+def raw_stream(n, dtype, bw, seed, cf32=False, noise=0.004):
+    """noise + rectangular pulses, quantised like the recorders' payload; returns the (n, 2) integer array (or the
+    complex64 vector) and the normalised complex128 samples the script would see"""
+    rng = np.random.default_rng(seed)
+    x = noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    def pulse(a, m, amp=0.4, dphi=21.0):
+        x[a:a + m] += amp * np.exp(1j * np.deg2rad(dphi) * np.arange(m))
+    pulse(300, 700)
+    pulse(5000, 40, dphi=-150.0)        # wraps past +-180 degrees
+    pulse(9000, 3000, amp=0.35)         # longer than the LDS cache, many tiles
+    pulse(20000, 60, amp=1.3)           # clips: saturated
+    pulse(30000 + 33, 64 * 9)           # word- and tile-crossing
+    k = np.arange(400)                   # dips to a tenth mid-pulse: below the leading, above the 3 dB trailing threshold
+    x[40000:40400] = 0.4 * np.exp(1j * 0.3 * k) * np.where((k > 180) & (k < 220), 0.1, 1.0)
+    pulse(n - 50, 50)                   # still active at the end: no PDW
+    if cf32:
+        v = x.astype(np.complex64)
+        return v, v.astype(np.complex128)
+    full = 2 ** (bw - 1)
+    iq = np.stack([np.clip(np.round(x.real * full), -full, full - 1), np.clip(np.round(x.imag * full), -full, full - 1)],
+                  axis=1).astype(dtype)
+    return iq, (iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)) / full
+
+
+@pytest.mark.parametrize("dtype,bw,n,noise,snr_db", [(np.int16, 12, 60000, 0.004, 18.0), (np.int16, 16, 65537, 0.004, 18.0),
+                                                     (np.int8, 8, 70001, 0.012, 12.0)])
+def test_raw_stream_pdws_match_oracle(oracle, dtype, bw, n, noise, snr_db):
+    """int8 has too little dynamic range for the script's 18 dB leading threshold (1.5 LSB of noise puts it at
+    ~100 LSB), so that case runs at 12 dB; its magnitudes are heavily tied, which the integer-key select handles"""
+    iq, x = raw_stream(n, dtype, bw, seed=bw + n % 7, noise=noise)
+    fs, fc, t0 = 56e6, 915e6, 1.7e9
+    got, nf = extract_pdws_raw(iq, fs, fc, t0, bit_width=bw, snr_threshold_db=snr_db, return_noise_floor=True)
+    want, want_nf = oracle.extract_pdws_raw(x, fs, fc, t0, snr_db=snr_db)
+    assert nf == pytest.approx(want_nf, rel=1e-14) and nf == pytest.approx(np.median(np.abs(x)), rel=1e-14)
+    assert len(want) >= 6
+    compare(got, want, fs)
+    assert (got["bin"] == 0).all()
+    assert got["sat"].any() and not got["sat"].all()
+    # the dip inside the 400-sample pulse stays above the trailing threshold: one PDW, not two
+    assert np.count_nonzero(np.abs(got["pw"] - 399 / fs) < 3 / fs) == 1
+
+
+def test_raw_stream_cf32_device_input_and_custom_thresholds(oracle):
+    import torch
+    v, x = raw_stream(50001, None, 0, seed=4, cf32=True)
+    got = extract_pdws_raw(torch.from_numpy(v).cuda(), 8e6, 0.0, 10.0, snr_threshold_db=12.0, trailing_threshold_db=6.0)
+    want, _ = oracle.extract_pdws_raw(x, 8e6, 0.0, 10.0, snr_db=12.0, trail_db=6.0)
+    assert len(want) >= 6
+    compare(got, want, 8e6)
+
+
+def test_raw_stream_at_recorder_size(oracle):
+    """2^24 samples on the device (a 0.3 s dwell at 56 Msps): pulse train of synth.pulsed_iq_torch.  Its pulses stand
+    14 dB (the script's dB/10 convention) above the noise floor, so the leading threshold is set to 12 dB."""
+    import torch
+    n = 1 << 24
+    iq = synth.pulsed_iq_torch(n, 12, device="cuda")
+    got, nf = extract_pdws_raw(iq, 56e6, 915e6, 0.0, snr_threshold_db=12.0, return_noise_floor=True)
+    h = iq.cpu().numpy()
+    x = (h[:, 0].astype(np.float64) + 1j * h[:, 1].astype(np.float64)) / 2048.0
+    want, want_nf = oracle.extract_pdws_raw(x, 56e6, 915e6, 0.0, snr_db=12.0, max_out=1 << 18)
+    assert nf == pytest.approx(want_nf, rel=1e-14)
+    assert len(want) >= 250           # 1 ms PRI over 0.3 s
+    compare(got, want, 56e6)
+
+
+def test_raw_stream_argument_checks_and_silence(oracle):
+    from sdr_channelizer_amd import _lib as L
+    iq = np.zeros((1000, 2), np.int16)
+    with pytest.raises(L.PfbError):
+        extract_pdws_raw(iq, 1e6, 0.0, 0.0, snr_threshold_db=3.0, trailing_threshold_db=18.0)
+    with pytest.raises(L.PfbError):
+        extract_pdws_raw(iq, 1e6, 0.0, 0.0, bit_width=17)
+    # all-zero stream: noise floor 0, both thresholds 0, so the script toggles on every sample (0 >= 0 starts a
+    # pulse, 0 <= 0 ends it): 500 two-sample "pulses" with NaN snr -- reproduced, not patched
+    got = extract_pdws_raw(iq, 1e6, 0.0, 0.0)
+    want, _ = oracle.extract_pdws_raw(np.zeros(1000, np.complex128), 1e6, 0.0, 0.0)
+    assert len(want) == 500
+    compare(got, want, 1e6)

@@ -182,3 +182,28 @@ def test_pdw_extraction_on_a_synthetic_pulse(oracle):
     # the reference's own indexing quirks change freq, nothing else
     q = [p for p in oracle.extract_pdws(y, fs_in, fc, t0, 15.0, matlab_quirks=True) if p["bin"] == 5][0]
     assert q["toa"] == p["toa"] and q["pw"] == p["pw"] and q["snr"] == p["snr"]
+
+
+def test_raw_pdw_extraction_known_answer(oracle):
+    """create_pdws.m:44-105 restated: one rectangular pulse on a noise floor, with a dip that stays above the 3 dB
+    trailing threshold (hysteresis) and a second pulse; fields follow the script's formulas."""
+    n, fs, fc, t0 = 4000, 1e6, 2e9, 50.0
+    rng = np.random.default_rng(5)
+    x = 0.001 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    k = np.arange(300)
+    x[1000:1300] = 0.5 * np.exp(1j * np.deg2rad(30.0) * k) * np.where((k >= 100) & (k < 110), 0.06, 1.0)
+    x[2000:2050] = 0.5 * np.exp(-1j * np.deg2rad(45.0) * np.arange(50))
+    pdws, nf = oracle.extract_pdws_raw(x, fs, fc, t0)
+    mag = np.abs(x)
+    assert nf == pytest.approx(np.median(mag), rel=1e-14)   # libm hypot vs numpy's: last-bit differences
+    assert len(pdws) == 2
+    p, q = pdws
+    assert p["toa"] == pytest.approx(1001 / fs + t0, abs=1e-9)      # 1-based index of the first sample (:67)
+    assert p["pw"] == pytest.approx(300 / fs, abs=1.5 / fs)          # the dip (0.03 > trail = 2 nf = 0.0024) does not end it
+    assert p["freq"] == pytest.approx(fc + fs * 30.0 / 360.0, rel=1e-9)
+    assert q["freq"] == pytest.approx(fc - fs * 45.0 / 360.0, rel=1e-9)
+    assert p["mag"] == pytest.approx(0.5, rel=0.05) and p["snr"] == pytest.approx(10 * np.log10(p["mag"] / nf))
+    assert not p["sat"] and p["bin"] == 0
+    # with the trailing threshold raised to the leading one the dip splits the first pulse
+    split, _ = oracle.extract_pdws_raw(x, fs, fc, t0, snr_db=18.0, trail_db=18.0)
+    assert len(split) == 3
