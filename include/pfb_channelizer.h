@@ -261,8 +261,10 @@ int pfb_pdw_extract_raw(const void* iq, uint64_t num_samples, uint32_t sample_fo
 /* Text of the most recent HIP failure inside pfb_pdw_extract on this thread. */
 const char* pfb_pdw_last_error_detail(void);
 /* How the last pfb_pdw_extract on this thread found the noise floors: 1 = sampled bracket + one
- * pass, 2 = full radix select (short input), 3 = the bracket check failed (heavily tied data) and
- * the full radix select ran after it.  All three give the exact medians; diagnostic only. */
+ * pass that also produced the edge masks, 4 = the same but the masks needed their own pass (too many
+ * samples near the threshold, or a median at the very edge of its bracket), 2 = full radix select
+ * (short input), 3 = the bracket check failed (heavily tied data) and the full radix select ran
+ * after it.  All give the exact medians and edges; diagnostic only. */
 int pfb_pdw_last_noise_floor_path(void);
 /* pfb_pdw_extract keeps its device scratch between calls (grow-only, per device; calls are
  * serialised on it).  This frees it: device_id >= 0 for one device, < 0 for all. */

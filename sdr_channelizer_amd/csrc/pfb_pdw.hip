@@ -38,7 +38,8 @@ constexpr int kTile = 512;        // frames per tile of the edge scan
 constexpr int kCand = 2048;       // candidate capacity per channel for the exact median finish
 constexpr int kPulseCache = 1024; // per-pulse values cached in LDS up to this many
 constexpr int kSampleRows = 65536; // rows sampled to bracket the median (below 8x this the full select runs)
-constexpr int kSamplePasses = 4;   // digits resolved on the sample: bracket edges to 2^-20 relative
+constexpr int kSamplePasses = 3;   // digits resolved on the sample: bracket edges to 2^-12 relative
+constexpr int kUndecided = 1 << 20; // samples too close to the threshold's bracket to classify before the median is known
 constexpr int kStage = 64;         // LDS staging slots per channel and workgroup in the bracket pass
 constexpr int kBracketRows = 1024; // rows per workgroup of the bracket pass
 constexpr double kRadToDeg = 57.295779513082320876798154814105;
@@ -80,16 +81,16 @@ __device__ __forceinline__ void hist_add(unsigned* h, unsigned digit, bool pred)
 // wave 0: four counters per lane, a shuffle scan, one lane owns the answer.
 template <class Get>
 __device__ double block_select(Get get, long long n, long long k, unsigned* hist /* [256] shared */,
-                               unsigned long long* pick /* [2] shared */) {
-  unsigned long long prefix = 0ull;
-  for (int pass = 0; pass < 8; ++pass) {
+                               unsigned long long* pick /* [2] shared */, int first_pass = 0,
+                               unsigned long long prefix = 0ull /* the first_pass digits every value shares */) {
+  for (int pass = first_pass; pass < 8; ++pass) {
     const int shift = 56 - 8 * pass;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0u;
     __syncthreads();
     for (long long i0 = 0; i0 < n; i0 += blockDim.x) {  // uniform trip count: hist_add uses wave-wide votes
       const long long i = i0 + threadIdx.x;
       const unsigned long long key = (i < n) ? dkey(get(i)) : 0ull;
-      const bool in = (i < n) && (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8)));
+      const bool in = (i < n) && (pass == first_pass || (key >> (shift + 8)) == (prefix >> (shift + 8)));
       hist_add(hist, (unsigned)(key >> shift) & 255u, in);
     }
     __syncthreads();
@@ -161,9 +162,12 @@ __device__ __forceinline__ long long sample_row(long long q, long long stride) {
 }
 
 // one 8-bit digit histogram pass over F rows (row q -> sample_row(q, stride)).
-// grid = (column groups of 64, row blocks); block = 256 (4 waves)
+// grid = (column groups of 64, row blocks, selects); block = 256 (4 waves).  blockIdx.z picks one of several
+// independent selects over the same rows (prefix[z][M], hist[z][M][256]): the two bracket ranks run together.
 __global__ void __launch_bounds__(256) pdw_hist_kernel(const float2* y, long long F, long long stride, int M, int pass,
                                                        const unsigned long long* prefix, unsigned* hist) {
+  prefix += (size_t)blockIdx.z * M;
+  hist += (size_t)blockIdx.z * M * 256;
   __shared__ unsigned h[256][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 256 * 64; i += 256) (&h[0][0])[i] = 0u;
@@ -279,46 +283,75 @@ __global__ void __launch_bounds__(256) pdw_median_finish_kernel(long long F, int
 // bits cleared / set): count and track the maximum of what lies below, gather what lies inside.
 // Candidates are staged per workgroup in LDS (lane = channel) and flushed as contiguous runs, so the
 // global append costs one atomic per channel and workgroup; a full stage spills element by element.
+//
+// The same pass writes the edge machine's comparison masks.  The threshold is gain * median, and the
+// median lies in [sqrt(lo), sqrt(hi)], so |y|^2 below lo * gain^2 is certainly under the threshold and
+// above hi * gain^2 certainly over it (both with a 1e-9 guard band); the few samples in between are
+// listed and classified exactly once the median is known (pdw_patch_kernel).  One word (64 frames)
+// per wave at a time, lane = channel; a workgroup covers kBracketRows frames.
 __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long long F, int M,
                                                           const unsigned long long* pre_lo, const unsigned long long* pre_hi,
-                                                          double* cand, unsigned cap, unsigned* cand_n,
+                                                          double gain2, double* cand, unsigned cap, unsigned* cand_n,
                                                           unsigned long long* below, unsigned long long* max_below,
-                                                          unsigned* flags) {
+                                                          unsigned long long* f0, unsigned long long* f1, long long words,
+                                                          unsigned long long* undecided, unsigned* und_n, unsigned* flags) {
   __shared__ double stage[kStage][64];
   __shared__ unsigned cnt[64], base[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 64) cnt[threadIdx.x] = 0u;
   __syncthreads();
   const int col = blockIdx.x * 64 + lane;
-  const long long r0 = (long long)blockIdx.y * kBracketRows;
-  const long long r1 = (r0 + kBracketRows < F) ? r0 + kBracketRows : F;
   constexpr unsigned long long kLow = (1ull << (64 - 8 * kSamplePasses)) - 1ull;
+  constexpr int kWordsPerBlock = kBracketRows / 64;
   if (col < M) {
     const unsigned long long lo = pre_lo[col] & ~kLow, hi = pre_hi[col] | kLow;
+    const double t2lo = dkey_inv(lo) * gain2 * (1.0 - 1e-9), t2hi = dkey_inv(hi) * gain2 * (1.0 + 1e-9);
     unsigned long long nb = 0ull, best = 0ull;
-    auto visit = [&](float2 v) {
-      const double m = mag2_of(v);
-      const unsigned long long k = dkey(m);
-      if (k < lo) {
-        ++nb;
-        best = k > best ? k : best;
-      } else if (k <= hi) {
-        const unsigned slot = atomicAdd(&cnt[lane], 1u);
-        if (slot < (unsigned)kStage) {
-          stage[slot][lane] = m;
-        } else {
-          const unsigned g = atomicAdd(&cand_n[col], 1u);
-          if (g < cap) cand[(size_t)col * cap + g] = m;
-          else atomicOr(flags, 1u);
+    for (int wi = wave; wi < kWordsPerBlock; wi += 4) {
+      const long long w = (long long)blockIdx.y * kWordsPerBlock + wi;
+      if (w >= words) break;
+      const long long r0 = w * 64;
+      unsigned long long over = 0ull;
+      auto visit = [&](float2 v, int i) {
+        const double m = mag2_of(v);
+        const unsigned long long k = dkey(m);
+        if (k < lo) {
+          ++nb;
+          best = k > best ? k : best;
+        } else if (k <= hi) {
+          const unsigned slot = atomicAdd(&cnt[lane], 1u);
+          if (slot < (unsigned)kStage) {
+            stage[slot][lane] = m;
+          } else {
+            const unsigned g = atomicAdd(&cand_n[col], 1u);
+            if (g < cap) cand[(size_t)col * cap + g] = m;
+            else atomicOr(flags, 1u);
+          }
+        }
+        if (m > t2hi) {
+          over |= 1ull << i;
+        } else if (m >= t2lo) {
+          const unsigned u = atomicAdd(und_n, 1u);
+          if (u < (unsigned)kUndecided) undecided[u] = (unsigned long long)(r0 + i) * (unsigned long long)M + (unsigned)col;
+          else atomicOr(flags, 4u);
+        }
+      };
+      unsigned long long pad = 0ull;  // frames past F: identity (f0 = 0, f1 = 1)
+      if (r0 + 64 <= F) {
+        for (int i = 0; i < 64; i += 4) {  // four rows in flight per lane
+          const float2 a = y[(r0 + i) * M + col], b = y[(r0 + i + 1) * M + col], c = y[(r0 + i + 2) * M + col],
+                       d = y[(r0 + i + 3) * M + col];
+          visit(a, i); visit(b, i + 1); visit(c, i + 2); visit(d, i + 3);
+        }
+      } else {
+        for (int i = 0; i < 64; ++i) {
+          if (r0 + i < F) visit(y[(r0 + i) * M + col], i);
+          else pad |= 1ull << i;
         }
       }
-    };
-    long long r = r0 + wave;
-    for (; r + 12 < r1; r += 16) {  // four rows in flight per lane
-      const float2 a = y[r * M + col], b = y[(r + 4) * M + col], c = y[(r + 8) * M + col], d = y[(r + 12) * M + col];
-      visit(a); visit(b); visit(c); visit(d);
+      f0[w * M + col] = over;
+      f1[w * M + col] = over | pad;
     }
-    for (; r < r1; r += 4) visit(y[r * M + col]);
     if (nb) atomicAdd(&below[col], nb);
     if (best) atomicMax(&max_below[col], best);
   }
@@ -341,31 +374,78 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
 }
 
 // exact order statistics among the gathered candidates; one workgroup per channel.  The median's rank
-// must fall inside the candidate set -- that is the proof the sampled bracket held it.
+// must fall inside the candidate set -- that is the proof the sampled bracket held it.  The digits
+// lo and hi share are known, so the select starts below them; the lower middle value of an even count
+// is the largest candidate below the upper one unless that one repeats.  Also checks that the threshold
+// really lies inside the band the provisional masks assumed (flag 8 if not).
 __global__ void __launch_bounds__(1024) pdw_bracket_finish_kernel(long long F, const double* cand, unsigned cap,
                                                                   const unsigned* cand_n, const unsigned long long* below,
-                                                                  const unsigned long long* max_below, double* nf,
+                                                                  const unsigned long long* max_below,
+                                                                  const unsigned long long* pre_lo,
+                                                                  const unsigned long long* pre_hi, double gain, double* nf,
                                                                   unsigned* flags) {
   __shared__ unsigned hist[256];
   __shared__ unsigned long long pick[2];
+  __shared__ unsigned long long lt_count, lt_max;
   const int col = blockIdx.x;
   const unsigned long long n = cand_n[col], b = below[col], target = (unsigned long long)(F / 2);
   if (n > cap || b > target || target - b >= n) {  // uniform over the workgroup
     if (threadIdx.x == 0) { atomicOr(flags, 2u); nf[col] = 0.0; }
     return;
   }
+  constexpr unsigned long long kLow = (1ull << (64 - 8 * kSamplePasses)) - 1ull;
+  const unsigned long long lo = pre_lo[col] & ~kLow, hi = pre_hi[col] | kLow;
+  int shared_digits = 0;
+  while (shared_digits < 8 && (lo >> (56 - 8 * shared_digits)) == (hi >> (56 - 8 * shared_digits))) ++shared_digits;
+  const unsigned long long known = shared_digits ? (lo & (~0ull << (64 - 8 * shared_digits))) : 0ull;
   const long long r = (long long)(target - b);
   const double* v = cand + (size_t)col * cap;
   auto get = [&](long long i) { return v[i]; };
-  const double v1 = block_select(get, (long long)n, r, hist, pick);
+  const double v1 = (shared_digits == 8) ? dkey_inv(lo) : block_select(get, (long long)n, r, hist, pick, shared_digits, known);
   double res;
   if (F & 1) {
     res = sqrt(v1);
   } else {
-    const double v0 = (r > 0) ? block_select(get, (long long)n, r - 1, hist, pick) : dkey_inv(max_below[col]);
+    double v0;
+    if (r == 0) {
+      v0 = dkey_inv(max_below[col]);
+    } else {
+      if (threadIdx.x == 0) { lt_count = 0ull; lt_max = 0ull; }
+      __syncthreads();
+      unsigned long long c = 0ull, mx = 0ull;
+      const unsigned long long k1 = dkey(v1);
+      for (long long i = threadIdx.x; i < (long long)n; i += blockDim.x) {
+        const unsigned long long k = dkey(v[i]);
+        if (k < k1) { ++c; mx = k > mx ? k : mx; }
+      }
+      if (c) { atomicAdd(&lt_count, c); atomicMax(&lt_max, mx); }
+      __syncthreads();
+      v0 = (lt_count == (unsigned long long)r) ? dkey_inv(lt_max) : v1;
+    }
     res = 0.5 * (sqrt(v0) + sqrt(v1));
   }
-  if (threadIdx.x == 0) nf[col] = res;
+  if (threadIdx.x == 0) {
+    nf[col] = res;
+    const double t2 = (res * gain) * (res * gain);
+    const double g2 = gain * gain;
+    if (!(t2 >= dkey_inv(lo) * g2 * (1.0 - 1e-10) && t2 <= dkey_inv(hi) * g2 * (1.0 + 1e-10))) atomicOr(flags, 8u);
+  }
+}
+
+// classify the listed samples now that the thresholds are known: set their bits in the masks
+__global__ void __launch_bounds__(256) pdw_patch_kernel(const float2* y, int M, const double* thr,
+                                                        const unsigned long long* undecided, const unsigned* und_n,
+                                                        unsigned long long* f0, unsigned long long* f1) {
+  const unsigned n = *und_n < (unsigned)kUndecided ? *und_n : (unsigned)kUndecided;
+  for (unsigned u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
+    const unsigned long long idx = undecided[u];
+    const long long row = (long long)(idx / (unsigned long long)M);
+    const int col = (int)(idx % (unsigned long long)M);
+    const double m = mag_of(y[idx]), t = thr[col];
+    const unsigned long long bit = 1ull << (row & 63);
+    if (m >= t) atomicOr(&f0[(row >> 6) * M + col], bit);
+    if (m > t) atomicOr(&f1[(row >> 6) * M + col], bit);
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -960,24 +1040,25 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
   const unsigned cap = sampled ? (unsigned)std::min<size_t>((size_t)F, 2 * expect + 4096) : 0u;
 
   const float2* d_y = nullptr;
-  unsigned *d_hist, *d_bucket, *d_cand_n, *d_flags;
-  unsigned long long *d_prefix, *d_prefix_hi, *d_rank, *d_below, *d_maxbelow;
+  unsigned *d_hist, *d_bucket, *d_cand_n, *d_flags, *d_und_n;
+  unsigned long long *d_prefix, *d_prefix_hi, *d_rank, *d_below, *d_maxbelow, *d_und;
   double *d_cand, *d_thr;
   EdgeStage e{};
   std::vector<unsigned> h_bucket(M);
   std::vector<unsigned long long> h_rank(M);
   std::vector<double> h_nf(M), h_thr(M), h_binf(M);
   unsigned h_flags = 0;
-  bool have_nf = false;
+  bool have_nf = false, masks_ready = false;
   int passes = 0;
+  const double gain = std::pow(10.0, snr_threshold_db / 10.0);  // :74-75 (dB applied to magnitude with /10)
   const int row_blocks = (int)std::min<long long>(1024, std::max<long long>(1, F / 256));
   const size_t cand_elems = std::max<size_t>((size_t)M * kCand, (size_t)M * cap);
 
   {
     size_t need = 0;
     if (mem == PFB_MEM_HOST) need += padded((size_t)F * M * sizeof(float2));
-    need += padded((size_t)M * 256 * sizeof(unsigned)) + 2 * padded(M * sizeof(unsigned)) + padded(sizeof(unsigned));
-    need += 5 * padded(M * sizeof(unsigned long long));
+    need += padded(2 * (size_t)M * 256 * sizeof(unsigned)) + 2 * padded(2 * M * sizeof(unsigned)) + 2 * padded(sizeof(unsigned));
+    need += 4 * padded(2 * M * sizeof(unsigned long long)) + padded((size_t)kUndecided * sizeof(unsigned long long));
     need += padded(cand_elems * sizeof(double)) + padded(M * sizeof(double));
     need += edge_stage_bytes(words, ntiles, M);
     PDW_TRY(arena_reserve(ws, need));
@@ -989,52 +1070,59 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
   } else {
     d_y = static_cast<const float2*>(y_in);
   }
-  d_hist = take<unsigned>(ws, (size_t)M * 256);
-  d_bucket = take<unsigned>(ws, M);
-  d_cand_n = take<unsigned>(ws, M);
+  d_hist = take<unsigned>(ws, 2 * (size_t)M * 256);  // [select][channel][digit]; the sample runs two selects at once
+  d_bucket = take<unsigned>(ws, 2 * (size_t)M);
+  d_cand_n = take<unsigned>(ws, 2 * (size_t)M);
   d_flags = take<unsigned>(ws, 1);
-  d_prefix = take<unsigned long long>(ws, M);
-  d_prefix_hi = take<unsigned long long>(ws, M);
-  d_rank = take<unsigned long long>(ws, M);
-  d_below = take<unsigned long long>(ws, M);
-  d_maxbelow = take<unsigned long long>(ws, M);
+  d_und_n = take<unsigned>(ws, 1);
+  d_prefix = take<unsigned long long>(ws, 2 * (size_t)M);
+  d_prefix_hi = d_prefix + M;
+  d_rank = take<unsigned long long>(ws, 2 * (size_t)M);
+  d_below = take<unsigned long long>(ws, 2 * (size_t)M);
+  d_maxbelow = take<unsigned long long>(ws, 2 * (size_t)M);
+  d_und = take<unsigned long long>(ws, (size_t)kUndecided);
   d_cand = take<double>(ws, cand_elems);
   d_thr = take<double>(ws, M);
   e = take_edge_stage(ws, words, ntiles, M, true);
 
-  PDW_TRY(hipMemsetAsync(d_hist, 0, (size_t)M * 256 * sizeof(unsigned), st));
+  PDW_TRY(hipMemsetAsync(d_hist, 0, 2 * (size_t)M * 256 * sizeof(unsigned), st));
 
   // ---- noise floor (:73), sampled bracket first
   if (sampled) {
-    const int sblocks = (int)std::min<long long>(1024, std::max<long long>(1, ns / 256));
-    for (int side = 0; side < 2; ++side) {  // radix select of the two bracket ranks on the sample
-      const long long k = side == 0 ? std::max<long long>(0, ns / 2 - delta) : std::min<long long>(ns - 1, ns / 2 + delta);
-      unsigned long long* pre = side == 0 ? d_prefix : d_prefix_hi;
-      std::fill(h_rank.begin(), h_rank.end(), (unsigned long long)k);
-      PDW_TRY(hipMemsetAsync(pre, 0, M * sizeof(unsigned long long), st));
-      PDW_TRY(hipMemcpyAsync(d_rank, h_rank.data(), M * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
-      PDW_TRY(hipStreamSynchronize(st));  // h_rank is reused by the next side
-      for (int ps = 0; ps < kSamplePasses; ++ps) {
-        hipLaunchKernelGGL(pdw_hist_kernel, dim3(cgroups, sblocks), dim3(256), 0, st, d_y, ns, stride, Mi, ps, pre, d_hist);
-        hipLaunchKernelGGL(pdw_pick_kernel, dim3((Mi + 63) / 64), dim3(64), 0, st, Mi, ps, d_hist, pre, d_rank, d_bucket,
-                           d_below);
-      }
+    const int sblocks = (int)std::min<long long>(1024, std::max<long long>(1, ns / 1024));  // few, long blocks: the 64 KB LDS histogram's clear and flush dominate a short one
+    // radix select of the two bracket ranks on the sample, both in the same launches (select 0 = low, 1 = high)
+    std::vector<unsigned long long> h_rank2(2 * (size_t)M);
+    std::fill(h_rank2.begin(), h_rank2.begin() + M, (unsigned long long)std::max<long long>(0, ns / 2 - delta));
+    std::fill(h_rank2.begin() + M, h_rank2.end(), (unsigned long long)std::min<long long>(ns - 1, ns / 2 + delta));
+    PDW_TRY(hipMemsetAsync(d_prefix, 0, 2 * (size_t)M * sizeof(unsigned long long), st));
+    PDW_TRY(hipMemcpyAsync(d_rank, h_rank2.data(), 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    PDW_TRY(hipStreamSynchronize(st));  // h_rank2 goes out of scope
+    for (int ps = 0; ps < kSamplePasses; ++ps) {
+      hipLaunchKernelGGL(pdw_hist_kernel, dim3(cgroups, sblocks, 2), dim3(256), 0, st, d_y, ns, stride, Mi, ps,
+                         (const unsigned long long*)d_prefix, d_hist);
+      hipLaunchKernelGGL(pdw_pick_kernel, dim3((2 * Mi + 63) / 64), dim3(64), 0, st, 2 * Mi, ps, d_hist, d_prefix, d_rank,
+                         d_bucket, d_below);
     }
-    PDW_TRY(hipMemsetAsync(d_below, 0, M * sizeof(unsigned long long), st));
+    PDW_TRY(hipMemsetAsync(d_below, 0, 2 * (size_t)M * sizeof(unsigned long long), st));
     PDW_TRY(hipMemsetAsync(d_maxbelow, 0, M * sizeof(unsigned long long), st));
     PDW_TRY(hipMemsetAsync(d_cand_n, 0, M * sizeof(unsigned), st));
     PDW_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
+    PDW_TRY(hipMemsetAsync(d_und_n, 0, sizeof(unsigned), st));
     hipLaunchKernelGGL(pdw_bracket_kernel, dim3(cgroups, (unsigned)((F + kBracketRows - 1) / kBracketRows)), dim3(256), 0, st,
-                       d_y, F, Mi, d_prefix, d_prefix_hi, d_cand, cap, d_cand_n, d_below, d_maxbelow, d_flags);
-    hipLaunchKernelGGL(pdw_bracket_finish_kernel, dim3(Mi), dim3(1024), 0, st, F, d_cand, cap, d_cand_n, d_below, d_maxbelow,
-                       e.nf, d_flags);
+                       d_y, F, Mi, (const unsigned long long*)d_prefix, (const unsigned long long*)d_prefix_hi, gain * gain,
+                       d_cand, cap, d_cand_n, d_below, d_maxbelow, e.f0, e.f1, words, d_und, d_und_n, d_flags);
+    hipLaunchKernelGGL(pdw_bracket_finish_kernel, dim3(Mi), dim3(1024), 0, st, F, (const double*)d_cand, cap,
+                       (const unsigned*)d_cand_n, (const unsigned long long*)d_below, (const unsigned long long*)d_maxbelow,
+                       (const unsigned long long*)d_prefix, (const unsigned long long*)d_prefix_hi, gain, e.nf, d_flags);
     PDW_TRY(hipGetLastError());
     PDW_TRY(hipMemcpyAsync(&h_flags, d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     PDW_TRY(hipMemcpyAsync(h_nf.data(), e.nf, M * sizeof(double), hipMemcpyDeviceToHost, st));
     PDW_TRY(hipStreamSynchronize(st));
+    masks_ready = (h_flags == 0);          // flags 4 / 8 only spoil the provisional masks, not the medians
+    h_flags &= 3u;
     have_nf = (h_flags == 0);
   }
-  g_pdw_path = have_nf ? 1 : (sampled ? 3 : 2);
+  g_pdw_path = have_nf ? (masks_ready ? 1 : 4) : (sampled ? 3 : 2);
   if (!have_nf) {  // full radix select of rank F/2, then the exact finish
     std::fill(h_rank.begin(), h_rank.end(), (unsigned long long)(F / 2));
     PDW_TRY(hipMemsetAsync(d_hist, 0, (size_t)M * 256 * sizeof(unsigned), st));
@@ -1062,7 +1150,6 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
     PDW_TRY(hipStreamSynchronize(st));
   }
   {
-    const double gain = std::pow(10.0, snr_threshold_db / 10.0);  // :74-75 (dB applied to magnitude with /10)
     for (uint32_t b = 0; b < M; ++b) h_thr[b] = h_nf[b] * gain;
     pfb_center_frequencies(M, fs_in, h_binf.data());              // :42, before fs is decimated
     if (noise_floor_out) std::memcpy(noise_floor_out, h_nf.data(), M * sizeof(double));
@@ -1071,8 +1158,13 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
   PDW_TRY(hipMemcpyAsync(e.binf, h_binf.data(), M * sizeof(double), hipMemcpyHostToDevice, st));
 
   // ---- edges (:85-135) and pulses (:98-132)
-  hipLaunchKernelGGL(pdw_mask_kernel, dim3(cgroups, (unsigned)((words + 3) / 4)), dim3(256), 0, st, d_y, F, Mi,
-                     (const double*)d_thr, e.f0, e.f1, words);
+  if (masks_ready) {  // the bracket pass left the masks; settle the few samples it could not classify
+    hipLaunchKernelGGL(pdw_patch_kernel, dim3(64), dim3(256), 0, st, d_y, Mi, (const double*)d_thr,
+                       (const unsigned long long*)d_und, (const unsigned*)d_und_n, e.f0, e.f1);
+  } else {
+    hipLaunchKernelGGL(pdw_mask_kernel, dim3(cgroups, (unsigned)((words + 3) / 4)), dim3(256), 0, st, d_y, F, Mi,
+                       (const double*)d_thr, e.f0, e.f1, words);
+  }
   PDW_TRY(hipGetLastError());
   rc = edges_and_pulses(ChanSrc{d_y, Mi}, Mi, ntiles, e, ws2, fs, fc, sample_start_time, flags, out, capacity, count, st);
 

@@ -21,3 +21,12 @@ for rep in range(4):
     got = extract_pdws(y, 56e6, 915e6, 0.0, decimation=D)
     dt = time.perf_counter() - t0
     print(f"PDW extraction: F={y.shape[0]} M={M}: {len(got)} pulses in {dt * 1e3:.1f} ms")
+
+# raw-stream extraction (create_pdws.m) on the same recorder stream; its pulses stand 14 dB (dB/10) above the floor
+from sdr_channelizer_amd.pdw import extract_pdws_raw  # noqa: E402
+
+for rep in range(4):
+    t0 = time.perf_counter()
+    got = extract_pdws_raw(iq, 56e6, 915e6, 0.0, snr_threshold_db=12.0)
+    dt = time.perf_counter() - t0
+    print(f"raw PDW extraction: n={n}: {len(got)} pulses in {dt * 1e3:.1f} ms")
