@@ -34,9 +34,11 @@
 
 namespace {
 
-constexpr int kTile = 512;        // frames per tile of the edge scan
+constexpr int kTile = 512;        // smallest tile of the edge scan, in frames (tiles grow with the stream, see tile_words_for)
 constexpr int kCand = 2048;       // candidate capacity per channel for the exact median finish
-constexpr int kPulseCache = 1024; // per-pulse values cached in LDS up to this many
+constexpr int kPulseCache = 1024; // per-pulse values cached in LDS up to this many (channelized: pulses are tens of frames)
+constexpr int kPulseCacheRaw = 7168; // same for the raw stream, whose pulses are thousands of samples (56 KB of LDS)
+constexpr int kCountingMedian = 512; // cached pulses up to this long take the O(n^2 / threads) counting median
 constexpr int kSampleRows = 65536; // rows sampled to bracket the median (below 8x this the full select runs)
 constexpr int kSamplePasses = 3;   // digits resolved on the sample: bracket edges to 2^-12 relative
 constexpr int kUndecided = 1 << 20; // samples too close to the threshold's bracket to classify before the median is known
@@ -60,20 +62,18 @@ __device__ __forceinline__ double dkey_inv(unsigned long long k) {
   return __longlong_as_double((long long)b);
 }
 
-// histogram increment with a wave-uniform fast path: when every participating lane of the wave has the
-// same digit (the common case while the decided prefix is still shared by all values) one lane adds the
-// lane count instead of 64 atomics serialising on one LDS word.  Lanes with pred == false do not count.
+// histogram increment with wave aggregation of the most likely digit: the lanes that share the first
+// participating lane's digit (all of them while the decided prefix is still common to every value, most
+// of them on noise-dominated data) are counted by one atomic instead of serialising on one LDS word; the
+// others add themselves.  Lanes with pred == false do not count.  Call with the whole wave converged.
 __device__ __forceinline__ void hist_add(unsigned* h, unsigned digit, bool pred) {
   const unsigned long long act = __ballot(pred);
   if (!act) return;
   const int leader = __ffsll((long long)act) - 1;
   const unsigned d0 = (unsigned)__shfl((int)digit, leader);
   const unsigned long long same = __ballot(pred && digit == d0);
-  if (same == act) {
-    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[d0], (unsigned)__popcll(act));
-  } else if (pred) {
-    atomicAdd(&h[digit], 1u);
-  }
+  if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[d0], (unsigned)__popcll(same));
+  else if (pred && digit != d0) atomicAdd(&h[digit], 1u);
 }
 
 // k-th smallest of n doubles produced by get(i), by 8 passes of 8-bit digits; the whole workgroup
@@ -122,14 +122,28 @@ __device__ double block_select(Get get, long long n, long long k, unsigned* hist
   return dkey_inv(prefix);
 }
 
+// MATLAB median.  For an even count the lower middle value is the largest value below the upper one,
+// unless the upper one repeats (fewer than n/2 values lie below it): one counting pass, not a second select.
 template <class Get>
 __device__ double block_median(Get get, long long n, unsigned* hist, unsigned long long* pick) {
   const double hi = block_select(get, n, n / 2, hist, pick);
   if (n & 1) return hi;
-  return 0.5 * (block_select(get, n, n / 2 - 1, hist, pick) + hi);
+  if (threadIdx.x == 0) { pick[0] = 0ull; pick[1] = 0ull; }
+  __syncthreads();
+  const unsigned long long kh = dkey(hi);
+  unsigned long long c = 0ull, mx = 0ull;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const unsigned long long k = dkey(get(i));
+    if (k < kh) { ++c; mx = k > mx ? k : mx; }
+  }
+  if (c) { atomicAdd(&pick[0], c); atomicMax(&pick[1], mx); }
+  __syncthreads();
+  const double lo = (pick[0] == (unsigned long long)(n / 2)) ? dkey_inv(pick[1]) : hi;
+  __syncthreads();
+  return 0.5 * (lo + hi);
 }
 
-// median of the n <= kPulseCache values in v[] (LDS) by rank counting: element i has rank
+// median of the n <= kCountingMedian values in v[] (LDS) by rank counting: element i has rank
 // #{v_j < v_i} + #{j < i : v_j == v_i}; the two middle ranks announce themselves.  No passes, two barriers.
 __device__ double cached_median(const double* v, int n, double* mid /* [2] shared */) {
   const int kh = n / 2, kl = kh - 1;
@@ -457,7 +471,7 @@ __global__ void __launch_bounds__(256) pdw_patch_kernel(const float2* y, int M, 
 // over the data records the two comparison bits per sample (64 samples per word); everything after that
 // -- tile summaries, the scan, the edge lists -- works on the bit masks, 1/64 of the data.
 
-constexpr int kTileWords = kTile / 64;
+constexpr int kTileWords = kTile / 64;  // smallest tile, in 64-sample words
 
 // Per-sample transition functions of one word: sample i maps state s to (s ? f1 : f0) bit i.  Returns the
 // prefix compositions: bit i of p0 / p1 = state after sample i when the word is entered inactive / active
@@ -513,15 +527,15 @@ __global__ void __launch_bounds__(256) pdw_mask_kernel(const float2* y, long lon
 // hand nothing has to be recounted once the scan has told which state each tile really starts in.
 // One thread per (tile, channel), channel fastest.
 __global__ void __launch_bounds__(256) pdw_tilefn_kernel(const unsigned long long* f0, const unsigned long long* f1, int M,
-                                                         long long ntiles, unsigned char* fn, ushort4* cnt) {
+                                                         long long ntiles, int tile_words, unsigned char* fn, ushort4* cnt) {
   const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
   if (g >= ntiles * M) return;
   const int col = (int)(g % M);
   const long long tile = g / M;
   int s0 = 0, s1 = 1;
   unsigned a0 = 0, e0 = 0, a1 = 0, e1 = 0;
-  for (int j = 0; j < kTileWords; ++j) {
-    const long long w = tile * kTileWords + j;
+  for (int j = 0; j < tile_words; ++j) {
+    const long long w = tile * tile_words + j;
     unsigned long long p0, p1;
     word_scan(f0[w * M + col], f1[w * M + col], p0, p1);
     const unsigned long long S0 = s0 ? p1 : p0, S1 = s1 ? p1 : p0;
@@ -535,29 +549,44 @@ __global__ void __launch_bounds__(256) pdw_tilefn_kernel(const unsigned long lon
 }
 
 // per column: incoming state of every tile, then the exclusive prefix of the edge counts of the
-// trajectory each tile really follows, and the column totals.  One wave per column: each lane owns a
-// contiguous segment of tiles; transition functions, then counts, are scanned across the wave (lane
-// order = time order) and each lane replays its segment.
-__global__ void __launch_bounds__(64) pdw_tilescan_kernel(int M, long long ntiles, const unsigned char* fn,
+// trajectory each tile really follows, and the column totals.  One workgroup of BT threads per column
+// (one wave when there are many columns, 16 waves for the one-column raw stream): each thread owns a
+// contiguous segment of tiles; transition functions, then counts, are scanned across the workgroup
+// (thread order = time order: shuffles inside a wave, wave totals through LDS) and each thread replays
+// its segment.
+__device__ __forceinline__ int compose_fn(int first, int then) {  // h(s) = then(first(s)), 2-bit encodings
+  return ((then >> (first & 1)) & 1) | (((then >> ((first >> 1) & 1)) & 1) << 1);
+}
+
+template <int BT>
+__global__ void __launch_bounds__(BT) pdw_tilescan_kernel(int M, long long ntiles, const unsigned char* fn,
                                                           const ushort4* cnt, unsigned char* state_in,
                                                           unsigned long long* off_s, unsigned long long* off_e,
                                                           unsigned long long* tot_s, unsigned long long* tot_e) {
-  const int col = blockIdx.x, lane = threadIdx.x;
-  const long long per = (ntiles + 63) / 64;
-  const long long t0 = lane * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
+  constexpr int NW = BT / 64;
+  __shared__ int wave_fn[NW];
+  __shared__ unsigned long long wave_a[NW], wave_b[NW];
+  const int col = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long per = (ntiles + BT - 1) / BT;
+  const long long t0 = (long long)tid * per < ntiles ? (long long)tid * per : ntiles;
+  const long long t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
   int f = 0x2;  // identity: f(0)=0, f(1)=1  -> bits (f0 | f1<<1) = 0b10
-  for (long long t = t0; t < t1; ++t) {
-    const int g = fn[t * M + col];  // apply g after f: h(s) = g(f(s))
-    f = ((g >> (f & 1)) & 1) | (((g >> ((f >> 1) & 1)) & 1) << 1);
-  }
-  // inclusive scan of function composition across lanes
+  for (long long t = t0; t < t1; ++t) f = compose_fn(f, fn[t * M + col]);
+  // inclusive scan of function composition across the wave, then across waves
   int inc = f;
   for (int d = 1; d < 64; d <<= 1) {
     const int prev = __shfl_up(inc, d);
-    if (lane >= d) inc = ((inc >> (prev & 1)) & 1) | (((inc >> ((prev >> 1) & 1)) & 1) << 1);
+    if (lane >= d) inc = compose_fn(prev, inc);
   }
   int exc = __shfl_up(inc, 1);
   if (lane == 0) exc = 0x2;
+  if (NW > 1) {
+    if (lane == 63) wave_fn[wave] = inc;
+    __syncthreads();
+    int before = 0x2;
+    for (int w = 0; w < wave; ++w) before = compose_fn(before, wave_fn[w]);
+    exc = compose_fn(before, exc);
+  }
   const int s_in = exc & 1;  // state entering my segment when the stream starts inactive: exc(0)
   int s = s_in;
   unsigned long long a = 0, b = 0;
@@ -573,6 +602,13 @@ __global__ void __launch_bounds__(64) pdw_tilescan_kernel(int M, long long ntile
     const unsigned long long pa = __shfl_up(ia, d), pb = __shfl_up(ib, d);
     if (lane >= d) { ia += pa; ib += pb; }
   }
+  if (NW > 1) {
+    if (lane == 63) { wave_a[wave] = ia; wave_b[wave] = ib; }
+    __syncthreads();
+    unsigned long long ba = 0, bb = 0;
+    for (int w = 0; w < wave; ++w) { ba += wave_a[w]; bb += wave_b[w]; }
+    ia += ba; ib += bb;
+  }
   unsigned long long ea = ia - a, eb = ib - b;  // exclusive
   s = s_in;
   for (long long t = t0; t < t1; ++t) {
@@ -582,12 +618,12 @@ __global__ void __launch_bounds__(64) pdw_tilescan_kernel(int M, long long ntile
     eb += s ? c.w : c.y;
     s = (fn[t * M + col] >> s) & 1;
   }
-  if (lane == 63) { tot_s[col] = ia; tot_e[col] = ib; }
+  if (tid == BT - 1) { tot_s[col] = ia; tot_e[col] = ib; }
 }
 
 // replay a tile from its incoming state and write the leading / trailing edge sample indices
 __global__ void __launch_bounds__(256) pdw_edges_kernel(const unsigned long long* f0, const unsigned long long* f1, int M,
-                                                        long long ntiles, const unsigned char* state_in,
+                                                        long long ntiles, int tile_words, const unsigned char* state_in,
                                                         const unsigned long long* off_s, const unsigned long long* off_e,
                                                         long long* starts, long long* ends) {
   const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -596,8 +632,8 @@ __global__ void __launch_bounds__(256) pdw_edges_kernel(const unsigned long long
   const long long tile = g / M;
   int s = state_in[g];
   unsigned long long os = off_s[g], oe = off_e[g];
-  for (int j = 0; j < kTileWords; ++j) {
-    const long long w = tile * kTileWords + j;
+  for (int j = 0; j < tile_words; ++j) {
+    const long long w = tile * tile_words + j;
     unsigned long long p0, p1;
     word_scan(f0[w * M + col], f1[w * M + col], p0, p1);
     const unsigned long long S = s ? p1 : p0, P = (S << 1) | (unsigned long long)s;
@@ -622,6 +658,7 @@ __global__ void pdw_rebase_kernel(int M, long long ntiles, unsigned long long* o
 // sample sources: where a (sample index, channel) pair finds its complex value
 
 struct ChanSrc {  // F x M channelizer output, frame-major complex64
+  static constexpr int kCache = kPulseCache;
   const float2* y;
   int M;
   __device__ __forceinline__ double mag(long long i, int col) const { return mag_of(y[i * M + col]); }
@@ -636,6 +673,7 @@ struct ChanSrc {  // F x M channelizer output, frame-major complex64
 // |x|^2 orders like I^2 + Q^2, which is an exact integer for the integer formats.
 template <int FMT>
 struct RawSrc {
+  static constexpr int kCache = kPulseCacheRaw;
   const void* p;
   double inv_scale;  // 2^-(bit_width-1); 1 for cf32
   __device__ __forceinline__ void reim(long long i, double& re, double& im) const {
@@ -682,14 +720,14 @@ struct RawSrc {
 // ---------------------------------------------------------------------------------
 // per pulse
 
-template <class Src>
+template <class Src, int CACHE>
 __global__ void __launch_bounds__(256) pdw_pulse_kernel(Src src, int M, const long long* starts, const long long* ends,
                                                         const unsigned long long* base_s, const unsigned long long* base_e,
                                                         const double* nf, const double* bin_freqs, double fs, double fc,
                                                         double t0, unsigned flags, pfb_pdw* out, unsigned long long capacity) {
   __shared__ unsigned hist[256];
   __shared__ unsigned long long pick[2];
-  __shared__ double cache[kPulseCache];
+  __shared__ double cache[CACHE];
   __shared__ double mid[2];
   __shared__ int sat_flag;
   const unsigned long long pid = blockIdx.x;
@@ -717,10 +755,11 @@ __global__ void __launch_bounds__(256) pdw_pulse_kernel(Src src, int M, const lo
 
   // :101 / :70 amplitude = median magnitude over toa..jj
   double amp;
-  if (n <= kPulseCache) {
+  if (n <= CACHE) {
     for (long long i = threadIdx.x; i < n; i += blockDim.x) cache[i] = src.mag(toa + i, b);
     __syncthreads();
-    amp = cached_median(cache, (int)n, mid);
+    amp = (n <= kCountingMedian) ? cached_median(cache, (int)n, mid)
+                                 : block_median([&](long long i) { return cache[i]; }, n, hist, pick);
   } else {
     amp = block_median([&](long long i) { return src.mag(toa + i, b); }, n, hist, pick);
   }
@@ -734,10 +773,11 @@ __global__ void __launch_bounds__(256) pdw_pulse_kernel(Src src, int M, const lo
     return d;
   };
   double med;
-  if (n - 1 <= kPulseCache) {
+  if (n - 1 <= CACHE) {
     for (long long i = threadIdx.x; i < n - 1; i += blockDim.x) cache[i] = dphi(i);
     __syncthreads();
-    med = cached_median(cache, (int)(n - 1), mid);
+    med = (n - 1 <= kCountingMedian) ? cached_median(cache, (int)(n - 1), mid)
+                                     : block_median([&](long long i) { return cache[i]; }, n - 1, hist, pick);
   } else {
     med = block_median(dphi, n - 1, hist, pick);
   }
@@ -772,11 +812,18 @@ __global__ void __launch_bounds__(256) pdw_raw_hist_kernel(Src src, long long n,
   __shared__ unsigned h[kRawBins];
   for (int i = threadIdx.x; i < kRawBins; i += 256) h[i] = 0u;
   __syncthreads();
-  const long long step = (long long)gridDim.x * 256;
-  for (long long i0 = (long long)blockIdx.x * 256; i0 < n; i0 += step) {
-    const long long i = i0 + threadIdx.x;
-    const unsigned long long k = (i < n) ? src.key(i) : 0ull;
-    hist_add(h, (unsigned)(k >> shift) & bins_mask, (i < n) && ((k & prefix_mask) == prefix));
+  const long long step = (long long)gridDim.x * 1024;
+  for (long long i0 = (long long)blockIdx.x * 1024; i0 < n; i0 += step) {  // four loads in flight per thread
+    unsigned long long k[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * 256 + threadIdx.x;
+      in[u] = i < n;
+      k[u] = in[u] ? src.key(i) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) hist_add(h, (unsigned)(k[u] >> shift) & bins_mask, in[u] && ((k[u] & prefix_mask) == prefix));
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kRawBins; i += 256)
@@ -789,10 +836,14 @@ __global__ void __launch_bounds__(256) pdw_raw_below_kernel(Src src, long long n
                                                             unsigned long long* below, unsigned long long* max_below) {
   unsigned long long nb = 0ull, best = 0ull;
   bool any = false;
-  const long long step = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += step) {
-    const unsigned long long k = src.key(i);
-    if (k < pivot) { ++nb; best = (any && best > k) ? best : k; any = true; }
+  const long long step = (long long)gridDim.x * 1024;
+  for (long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += step) {  // four loads in flight
+    unsigned long long k[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) k[u] = (i0 + u * 256 < n) ? src.key(i0 + u * 256) : ~0ull;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k[u] < pivot) { ++nb; best = (any && best > k[u]) ? best : k[u]; any = true; }
   }
   if (any) { atomicAdd(below, nb); atomicMax(max_below, best); }
 }
@@ -806,16 +857,23 @@ __global__ void __launch_bounds__(256) pdw_raw_mask_kernel(Src src, long long n,
   const long long w0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
   if (w0 >= words) return;
   unsigned long long a = 0ull, b = 0ull;
-  for (int i = 0; i < 64; ++i) {
-    const long long sidx = (w0 + i) * 64 + lane;
-    bool ge = false, gt = true;  // past the end: identity
-    if (sidx < n) {
-      const double m = src.mag(sidx, 0);
-      ge = m >= lead;
-      gt = m > trail;
+  for (int i0 = 0; i0 < 64; i0 += 8) {  // eight loads in flight per lane
+    bool ge[8], gt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long sidx = (w0 + i0 + u) * 64 + lane;
+      ge[u] = false; gt[u] = true;  // past the end: identity
+      if (sidx < n) {
+        const double m = src.mag(sidx, 0);
+        ge[u] = m >= lead;
+        gt[u] = m > trail;
+      }
     }
-    const unsigned long long wa = __ballot(ge), wb = __ballot(gt);
-    if (lane == i) { a = wa; b = wb; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned long long wa = __ballot(ge[u]), wb = __ballot(gt[u]);
+      if (lane == i0 + u) { a = wa; b = wb; }
+    }
   }
   if (w0 + lane < words) { f0[w0 + lane] = a; f1[w0 + lane] = b; }
 }
@@ -937,7 +995,7 @@ EdgeStage take_edge_stage(Arena& ws, long long words, long long ntiles, uint32_t
 // masks (e.f0, e.f1) and noise floors (e.nf) are on the device: tile summaries, scan, edge lists, one
 // workgroup per pulse, PDWs back to the host.
 template <class Src>
-int edges_and_pulses(Src src, int Mi, long long ntiles, const EdgeStage& e, Arena& ws2, double fs, double fc, double t0,
+int edges_and_pulses(Src src, int Mi, long long ntiles, int tile_words, const EdgeStage& e, Arena& ws2, double fs, double fc, double t0,
                      unsigned flags, pfb_pdw* out, uint64_t capacity, uint64_t* count, hipStream_t st) {
   int rc = PFB_OK;
   const uint32_t M = (uint32_t)Mi;
@@ -946,9 +1004,14 @@ int edges_and_pulses(Src src, int Mi, long long ntiles, const EdgeStage& e, Aren
   unsigned long long total_s = 0, total_e = 0;
   const unsigned tblocks = (unsigned)((tm + 255) / 256);
   hipLaunchKernelGGL(pdw_tilefn_kernel, dim3(tblocks), dim3(256), 0, st, (const unsigned long long*)e.f0,
-                     (const unsigned long long*)e.f1, Mi, ntiles, e.fn, e.cnt);
-  hipLaunchKernelGGL(pdw_tilescan_kernel, dim3(Mi), dim3(64), 0, st, Mi, ntiles, (const unsigned char*)e.fn,
-                     (const ushort4*)e.cnt, e.state, e.off_s, e.off_e, e.tot, e.tot + M);
+                     (const unsigned long long*)e.f1, Mi, ntiles, tile_words, e.fn, e.cnt);
+  if (Mi >= 32) {
+    hipLaunchKernelGGL(pdw_tilescan_kernel<64>, dim3(Mi), dim3(64), 0, st, Mi, ntiles, (const unsigned char*)e.fn,
+                       (const ushort4*)e.cnt, e.state, e.off_s, e.off_e, e.tot, e.tot + M);
+  } else {  // few columns: the parallelism has to come from time
+    hipLaunchKernelGGL(pdw_tilescan_kernel<1024>, dim3(Mi), dim3(1024), 0, st, Mi, ntiles, (const unsigned char*)e.fn,
+                       (const ushort4*)e.cnt, e.state, e.off_s, e.off_e, e.tot, e.tot + M);
+  }
   PDW_TRY(hipGetLastError());
   PDW_TRY(hipMemcpyAsync(h_tot.data(), e.tot, 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   PDW_TRY(hipStreamSynchronize(st));
@@ -968,10 +1031,10 @@ int edges_and_pulses(Src src, int Mi, long long ntiles, const EdgeStage& e, Aren
     hipLaunchKernelGGL(pdw_rebase_kernel, dim3(tblocks), dim3(256), 0, st, Mi, ntiles, e.off_s, e.off_e,
                        (const unsigned long long*)e.base, (const unsigned long long*)(e.base + M));
     hipLaunchKernelGGL(pdw_edges_kernel, dim3(tblocks), dim3(256), 0, st, (const unsigned long long*)e.f0,
-                       (const unsigned long long*)e.f1, Mi, ntiles, (const unsigned char*)e.state,
+                       (const unsigned long long*)e.f1, Mi, ntiles, tile_words, (const unsigned char*)e.state,
                        (const unsigned long long*)e.off_s, (const unsigned long long*)e.off_e, d_starts, d_ends);
     if (n_out > 0) {
-      hipLaunchKernelGGL(pdw_pulse_kernel<Src>, dim3((unsigned)n_out), dim3(256), 0, st, src, Mi, (const long long*)d_starts,
+      hipLaunchKernelGGL((pdw_pulse_kernel<Src, Src::kCache>), dim3((unsigned)n_out), dim3(256), 0, st, src, Mi, (const long long*)d_starts,
                          (const long long*)d_ends, (const unsigned long long*)e.base, (const unsigned long long*)(e.base + M),
                          (const double*)e.nf, (const double*)e.binf, fs, fc, t0, flags, d_out, n_out);
       PDW_TRY(hipGetLastError());
@@ -981,6 +1044,16 @@ int edges_and_pulses(Src src, int Mi, long long ntiles, const EdgeStage& e, Aren
   }
 done:
   return rc;
+}
+
+// Tile length of the edge scan, in words: the scan kernel walks a column's tiles with one workgroup, so
+// long streams get longer tiles (at most 2^14 tiles per column up to 2^30 samples); the per-tile edge counts are 16-bit, which
+// caps a tile at 2^16 samples.
+int tile_words_for(long long samples) {
+  const long long w = (samples + 63) / 64;
+  int tw = kTileWords;
+  while (tw < 1024 && w / tw > 16384) tw *= 2;
+  return tw;
 }
 
 // RAII: select the device for the call, restore on exit
@@ -1025,8 +1098,9 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const long long F = (long long)frames;
   const int Mi = (int)M;
-  const long long ntiles = (F + kTile - 1) / kTile;
-  const long long words = ntiles * kTileWords;  // whole tiles; the tail is identity-padded
+  const int tile_words = tile_words_for(F);
+  const long long ntiles = (F + 64ll * tile_words - 1) / (64ll * tile_words);
+  const long long words = ntiles * tile_words;  // whole tiles; the tail is identity-padded
   const int cgroups = (Mi + 63) / 64;
   const double fs = fs_in / (double)decimation;  // :62
   int rc = PFB_OK;
@@ -1108,7 +1182,7 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
     PDW_TRY(hipMemsetAsync(d_cand_n, 0, M * sizeof(unsigned), st));
     PDW_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
     PDW_TRY(hipMemsetAsync(d_und_n, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(pdw_bracket_kernel, dim3(cgroups, (unsigned)((F + kBracketRows - 1) / kBracketRows)), dim3(256), 0, st,
+    hipLaunchKernelGGL(pdw_bracket_kernel, dim3(cgroups, (unsigned)((words * 64 + kBracketRows - 1) / kBracketRows)), dim3(256), 0, st,
                        d_y, F, Mi, (const unsigned long long*)d_prefix, (const unsigned long long*)d_prefix_hi, gain * gain,
                        d_cand, cap, d_cand_n, d_below, d_maxbelow, e.f0, e.f1, words, d_und, d_und_n, d_flags);
     hipLaunchKernelGGL(pdw_bracket_finish_kernel, dim3(Mi), dim3(1024), 0, st, F, (const double*)d_cand, cap,
@@ -1166,7 +1240,7 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
                        (const double*)d_thr, e.f0, e.f1, words);
   }
   PDW_TRY(hipGetLastError());
-  rc = edges_and_pulses(ChanSrc{d_y, Mi}, Mi, ntiles, e, ws2, fs, fc, sample_start_time, flags, out, capacity, count, st);
+  rc = edges_and_pulses(ChanSrc{d_y, Mi}, Mi, ntiles, tile_words, e, ws2, fs, fc, sample_start_time, flags, out, capacity, count, st);
 
 done:
   (void)hipStreamSynchronize(st);
@@ -1181,7 +1255,7 @@ template <int FMT>
 int extract_raw(const void* d_iq, long long n, double inv_scale, double fs, double fc, double t0, double lead_db,
                 double trail_db, pfb_pdw* out, uint64_t capacity, uint64_t* count, double* noise_floor_out, Arena& ws,
                 Arena& ws2, const EdgeStage& e, unsigned* d_hist, unsigned long long* d_pair, long long words,
-                long long ntiles, hipStream_t st) {
+                long long ntiles, int tile_words, hipStream_t st) {
   int rc = PFB_OK;
   const RawSrc<FMT> src{d_iq, inv_scale};
   (void)ws;
@@ -1238,7 +1312,7 @@ int extract_raw(const void* d_iq, long long n, double inv_scale, double fs, doub
   hipLaunchKernelGGL(pdw_raw_mask_kernel<RawSrc<FMT>>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, src, n, lead,
                      trail, e.f0, e.f1, words);
   PDW_TRY(hipGetLastError());
-  rc = edges_and_pulses(src, 1, ntiles, e, ws2, fs, fc, t0, 0u, out, capacity, count, st);
+  rc = edges_and_pulses(src, 1, ntiles, tile_words, e, ws2, fs, fc, t0, 0u, out, capacity, count, st);
 done:
   return rc;
 }
@@ -1268,8 +1342,9 @@ extern "C" int pfb_pdw_extract_raw(const void* iq, uint64_t num_samples, uint32_
   Arena& ws2 = g_ws[dev][1];
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const long long n = (long long)num_samples;
-  const long long ntiles = (n + kTile - 1) / kTile;
-  const long long words = ntiles * kTileWords;
+  const int tile_words = tile_words_for(n);
+  const long long ntiles = (n + 64ll * tile_words - 1) / (64ll * tile_words);
+  const long long words = ntiles * tile_words;
   const size_t bps = sample_format == PFB_FMT_INT8_IQ ? 2 : sample_format == PFB_FMT_INT16_IQ ? 4 : 8;
   const double inv_scale = sample_format == PFB_FMT_CF32 ? 1.0 : std::ldexp(1.0, -((int)bit_width - 1));
   int rc = PFB_OK;
@@ -1290,15 +1365,15 @@ extern "C" int pfb_pdw_extract_raw(const void* iq, uint64_t num_samples, uint32_
   switch (sample_format) {
     case PFB_FMT_INT8_IQ:
       rc = extract_raw<PFB_FMT_INT8_IQ>(d_iq, n, inv_scale, fs, fc, sample_start_time, snr_threshold_db, trailing_threshold_db,
-                                        out, capacity, count, noise_floor_out, ws, ws2, e, d_hist, d_pair, words, ntiles, st);
+                                        out, capacity, count, noise_floor_out, ws, ws2, e, d_hist, d_pair, words, ntiles, tile_words, st);
       break;
     case PFB_FMT_INT16_IQ:
       rc = extract_raw<PFB_FMT_INT16_IQ>(d_iq, n, inv_scale, fs, fc, sample_start_time, snr_threshold_db, trailing_threshold_db,
-                                         out, capacity, count, noise_floor_out, ws, ws2, e, d_hist, d_pair, words, ntiles, st);
+                                         out, capacity, count, noise_floor_out, ws, ws2, e, d_hist, d_pair, words, ntiles, tile_words, st);
       break;
     default:
       rc = extract_raw<PFB_FMT_CF32>(d_iq, n, inv_scale, fs, fc, sample_start_time, snr_threshold_db, trailing_threshold_db,
-                                     out, capacity, count, noise_floor_out, ws, ws2, e, d_hist, d_pair, words, ntiles, st);
+                                     out, capacity, count, noise_floor_out, ws, ws2, e, d_hist, d_pair, words, ntiles, tile_words, st);
       break;
   }
 done:
