@@ -144,7 +144,7 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
     p.experiment = h->opt_experiment;
     p.grid_override = h->opt_grid;
     p.tile_waves = h->opt_tile_waves;
-    const bool want_fast = h->fast && h->layout == PFB_LAYOUT_FRAME_MAJOR && h->opt_kernel != 1;
+    const bool want_fast = h->fast && h->opt_kernel != 1;
     if (h->opt_kernel == 2 && !want_fast) return PFB_ERR_UNSUPPORTED;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (h->opt_profile && h->ev_used < 4096) {
@@ -162,6 +162,7 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
       int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
       fpb = ((fpb + c - 1) / c) * c;
       p.schedule = h->opt_schedule >= 0 ? h->opt_schedule : h->fast->default_schedule;
+      if (h->layout == PFB_LAYOUT_CHANNEL_MAJOR) p.schedule = 0;  // the channel-major instantiation is the sliding-run kernel
       if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
       if (p.schedule == 4) {
         if (h->opt_frames_per_block <= 0) fpb = 64;
@@ -347,7 +348,7 @@ int pfb_create(const pfb_config* cfg, pfb_handle** out) {
   h->device = dev;
   h->bps = pfb::bytes_per_sample(h->fmt);
   h->hist_samples = (int)(M * P + D);
-  h->fast = pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt);
+  h->fast = pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt, 0, h->layout == PFB_LAYOUT_CHANNEL_MAJOR);
 
   DeviceGuard g(dev);
   const size_t L = (size_t)M * P;
@@ -602,7 +603,8 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
     case PFB_OPT_VARIANT: {
       if (value < 0 || value > 16) return PFB_ERR_BAD_ARG;
       if ((int)value == h->opt_variant) return PFB_OK;
-      const pfb::FastKernelInfo* f = pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt, (int)value);
+      const pfb::FastKernelInfo* f =
+          pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt, (int)value, h->layout == PFB_LAYOUT_CHANNEL_MAJOR);
       if (!f) return PFB_ERR_UNSUPPORTED;
       DeviceGuard g(h->device);
       HIP_TRY(hipStreamSynchronize(h->stream));  // the old tables may still be in use

@@ -88,8 +88,9 @@ struct FastKernelInfo {
   int default_frames_per_block;
   int cols_per_thread;     // CPT: vector-load alignment requirement
   int default_schedule;    // measured best schedule for this instantiation (PFB_OPT_SCHEDULE = -1)
+  bool channel_major_ok;   // has a channel-major instantiation
 };
-const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant = 0);
+const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant = 0, bool channel_major = false);
 
 hipError_t launch_generic(const KernelParams& p, hipStream_t s);
 hipError_t launch_update_history(const void* old_hist, const void* in, long long n_in, void* new_hist,

@@ -254,7 +254,9 @@ struct FastCfg {
 
 // ---------------------------------------------------------------------------------
 
-template <class K>
+// CM = channel-major output, out[k * out_ld + out_frame0 + m] (MATLAB's column-major F x M): its own
+// instantiation, so the extra address arithmetic never costs the frame-major kernels a register.
+template <class K, bool CM = false>
 struct FastKernel {
   using ST = SampleT<K::FMT>;
   using raw_t = typename ST::raw_t;
@@ -379,7 +381,34 @@ struct FastKernel {
               return rowp + col_of(kk + k * KK);
             }
           };
-          if (p.flags & PFB_FLAG_MAGNITUDE) {  // fused abs(): 4 bytes per channel instead of 8
+          if constexpr (CM || (!K::POW2 && K::NT == 64)) {
+            // Channel-major: a frame-chunk's C frames of a channel are C consecutive elements, so a store
+            // instruction still fills whole 32/64-byte runs (its lanes differ in fc).  The R addresses are
+            // K columns apart (wrapping at M under fftshift); they are produced one at a time -- the opaque
+            // asm keeps the compiler from materialising all R 64-bit addresses ahead of the butterfly,
+            // which spilled.  The single-wave frame-major kernels with a non-power-of-two M (56) take the same
+            // route with column stride 1 (+5 %); the 576-thread M=560 kernel measured 7 % slower that way.
+            const bool mag = (p.flags & PFB_FLAG_MAGNITUDE) != 0;
+            const long long esz = mag ? 4 : 8;
+            const long long cs = CM ? p.out_ld : 1;  // elements between adjacent channels
+            int col = col_of(kk);
+            char* ptr = reinterpret_cast<char*>(p.out) + ((long long)col * cs + (CM ? p.out_frame0 + f : f * M)) * esz;
+            const long long step = (long long)KK * cs * esz, wrap = (long long)M * cs * esz;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+              v2f v = x[k];
+              if (mag) {
+                *reinterpret_cast<float*>(ptr) = sqrtf(v.x * v.x + v.y * v.y);
+              } else {
+                if (flip_odd && ((kk + k * KK) & 1)) v = -v;
+                store_c64(reinterpret_cast<float2*>(ptr), v, p.nontemporal);
+              }
+              asm volatile("" : "+v"(ptr) : : "memory");
+              col += KK;
+              ptr += step;
+              if (col >= M) { col -= M; ptr -= wrap; }
+            }
+          } else if (p.flags & PFB_FLAG_MAGNITUDE) {  // fused abs(): 4 bytes per channel instead of 8
             float* rowm = reinterpret_cast<float*>(p.out) + f0 * M + fc * M;
 #pragma unroll
             for (int k = 0; k < R; ++k) *slot(rowm, k) = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
@@ -880,10 +909,15 @@ hipError_t init_tables(const float* taps, const float2* tw, float* taps_lane, fl
   return hipGetLastError();
 }
 
+// plans whose channel-major instantiation does not fit their register budget (the 1024-thread cfg4 plan sits
+// at its 128-VGPR ceiling already): channel-major handles get the shape's next registered plan instead
 template <class K>
+constexpr bool kChannelMajorOk = K::NT < 1024;
+
+template <class K, bool CM = false>
 __global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_fast_kernel(const KernelParams p) {
   __shared__ float2 lds[K::LDS_ELEMS];
-  FastKernel<K>::run(p, lds);
+  FastKernel<K, CM>::run(p, lds);
 }
 
 template <class K>
@@ -978,6 +1012,15 @@ hipError_t launch_strided(const KernelParams& p, hipStream_t s) {  // persistent
 template <class K>
 hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   if (p.frames <= 0) return hipSuccess;
+  if (p.layout == PFB_LAYOUT_CHANNEL_MAJOR) {  // sliding runs only; the other schedules are frame-major tuning
+    if constexpr (kChannelMajorOk<K>) {
+      const long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
+      hipLaunchKernelGGL((pfb_fast_kernel<K, true>), dim3((unsigned)nb), dim3(K::NT), 0, s, p);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;  // find_fast_kernel never hands this plan to a channel-major handle
+    }
+  }
   // (measured on cfg3, cfg5 and M=56 too: slower than their sliding runs, so only the M=64 kernels carry it)
   if constexpr (K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::M == 64) {
     if (p.schedule == 4) {  // FIR / FFT wave pairs: tile_waves = pairs per workgroup, frames_per_block = run length

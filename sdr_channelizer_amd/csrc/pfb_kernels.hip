@@ -232,7 +232,7 @@ template <class K>
 constexpr FastEntry entry(const char* name, int default_fpb, int default_schedule) {
   return FastEntry{K::M, K::P, K::D, K::FMT,
                    FastKernelInfo{&launch_fast<K>, &init_tables<K>, K::TAPS_LANE_FLOATS, K::TW_LANE_ELEMS, name, K::C,
-                                  default_fpb, K::CPT, default_schedule}};
+                                  default_fpb, K::CPT, default_schedule, kChannelMajorOk<K>}};
 }
 
 static const FastEntry kFastTable[] = {
@@ -250,9 +250,10 @@ static const FastEntry kFastTable[] = {
     entry<Cfg560x12i8>("pfb_fast<M560,P12,D560,int8>", 252, 0),
 };
 
-const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant) {
+const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant, bool channel_major) {
   for (const FastEntry& e : kFastTable)
-    if (e.M == M && e.P == P && e.D == D && e.fmt == fmt && variant-- == 0) return &e.info;
+    if (e.M == M && e.P == P && e.D == D && e.fmt == fmt && (!channel_major || e.info.channel_major_ok) && variant-- == 0)
+      return &e.info;
   return nullptr;
 }
 

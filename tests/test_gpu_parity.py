@@ -112,16 +112,43 @@ def test_switches(oracle, M, P, D, kw):
     assert rel(y, want) < REL_TOL
 
 
-@pytest.mark.parametrize("M,P,D", [(64, 12, 64), (16, 4, 8)])
-def test_channel_major_layout(oracle, M, P, D):
-    iq = synth.pulsed_iq_numpy(D * 333, 12, np.int16, seed=5)
+@pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (16, 4, 8, "int16", 12), (256, 8, 256, "int8", 8),
+                                          (1024, 16, 1024, "int16", 16), (128, 12, 64, "int16", 12),
+                                          (56, 12, 56, "int16", 12), (560, 12, 560, "int16", 12)])
+def test_channel_major_layout(oracle, M, P, D, fmt, bw):
+    """PFB_LAYOUT_CHANNEL_MAJOR = MATLAB's column-major F x M.  Every fused shape has a channel-major
+    instantiation of its sliding-run kernel; (16, 4, 8) has no fused path and takes the generic kernel."""
+    iq = synth.pulsed_iq_numpy(D * 333, bw, np.int8 if fmt == "int8" else np.int16, seed=5)
     h = oracle.design_prototype(M, P).astype(np.float32)
-    with Channelizer(M, taps=h, decimation=D, bit_width=12, channel_major=True, fftshift=True) as ch:
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, channel_major=True, fftshift=True,
+                     derotate=(D != M)) as ch:
         ch.set_option(L.PFB_OPT_HOST_CHUNK_SAMPLES, D * 100)  # several staging chunks
         y = ch(iq)
-    want = oracle_run(oracle, iq, h, M, P, D, 12, fftshift=True)
+        assert ch.last_kernel.startswith("pfb_fast") == (M != 16)
+        ch.reset()
+        ch.set_option(L.PFB_OPT_KERNEL, 1)
+        y_generic = ch(iq)
+    want = oracle_run(oracle, iq, h, M, P, D, bw, fftshift=True, derotate=(D != M))
     assert y.shape == (M, want.shape[0])
     assert rel(y.T, want) < REL_TOL
+    assert rel(y, y_generic) < 2e-6
+
+
+def test_channel_major_device_path_is_bit_identical_to_frame_major():
+    """same arithmetic, different store addresses: the transposed frame-major result, bit for bit; cut into calls too"""
+    import torch
+    M, P = 64, 12
+    n = M * 5000 + 13
+    iq = synth.pulsed_iq_torch(n, 12, device="cuda")
+    h = np.random.default_rng(4).standard_normal(M * P).astype(np.float32) / M
+    with Channelizer(M, taps=h, bit_width=12) as a, Channelizer(M, taps=h, bit_width=12, channel_major=True) as b:
+        a.set_option(L.PFB_OPT_SCHEDULE, 0)
+        fm = a(iq)
+        cm = b(iq)
+        assert torch.equal(cm, fm.T.contiguous()) and cm.shape == (M, n // M)
+        b.reset()
+        parts = [b(iq[s:e]) for s, e in ((0, M * 1000 + 7), (M * 1000 + 7, M * 1001), (M * 1001, n))]
+        assert torch.equal(torch.cat([p_ for p_ in parts if p_.numel()], dim=1), cm)
 
 
 @pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (128, 12, 64, "int16", 12), (56, 12, 56, "int16", 12),

@@ -28,6 +28,7 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--workload", default="64,12,64,int16,12")
 ap.add_argument("--magnitude", action="store_true")
+ap.add_argument("--channel-major", action="store_true", help="MATLAB's column-major F x M output")
 ap.add_argument("--out-offset-kib", type=int, default=0, help="shift the output buffer start by this many KiB")
 ap.add_argument("--exact-out", action="store_true", help="allocate exactly frames*M outputs like bench.py")
 ap.add_argument("cases", nargs="+")
@@ -39,14 +40,17 @@ n = 1 << a.log2_samples
 dev = torch.device("cuda", 0)
 iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device=dev)
 odt = torch.float32 if a.magnitude else torch.complex64
-if a.exact_out:
+if a.channel_major:
+    out = torch.empty((M, n // D + 1), dtype=odt, device=dev)  # +1: a carried tail can complete one more frame
+elif a.exact_out:
     out = torch.empty((n // D, M), dtype=odt, device=dev)
 else:
     pad_rows = (a.out_offset_kib * 1024) // (M * (4 if a.magnitude else 8)) + 1
     big = torch.empty((n // D + 1 + pad_rows, M), dtype=odt, device=dev)
     out = big[pad_rows - 1:]
 print(f"# in ptr {iq.data_ptr():#x} out ptr {out.data_ptr():#x} delta {(out.data_ptr() - iq.data_ptr()) / 2**20:.3f} MiB")
-ch = Channelizer(M, taps=design_prototype(M, P), decimation=D, sample_format=fmt, bit_width=bw, magnitude=a.magnitude)
+ch = Channelizer(M, taps=design_prototype(M, P), decimation=D, sample_format=fmt, bit_width=bw, magnitude=a.magnitude,
+                 channel_major=a.channel_major)
 ch.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 cases = []
 for c in a.cases:
