@@ -1022,7 +1022,7 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
     }
   }
   // (measured on cfg3, cfg5 and M=56 too: slower than their sliding runs, so only the M=64 kernels carry it)
-  if constexpr (K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::M == 64) {
+  if constexpr (K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::M == 64 && K::C == 8) {
     if (p.schedule == 4) {  // FIR / FFT wave pairs: tile_waves = pairs per workgroup, frames_per_block = run length
       const int key = p.tile_waves * 1000 + p.frames_per_block;
       if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64) {  // tuning sweep set (cfg2 only, keeps build time sane)
@@ -1045,7 +1045,7 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       }
     }
   }
-  if constexpr (K::NT == 64) {
+  if constexpr (K::NT == 64 && K::C == 8 && !K::PINGPONG) {
     if (p.schedule == 3) {  // shared-halo sliding windows: tile_waves runs of frames_per_block frames
       const int key = p.tile_waves * 1000 + p.frames_per_block;
       if (key == 8024) return launch_shared<K, 8, 24>(p, s);
@@ -1061,7 +1061,7 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       return launch_shared<K, 8, 24>(p, s);  // any other shape: the tuned default
     }
   }
-  if constexpr (K::NT == 64 && K::M == 64 && K::FMT == PFB_FMT_INT16_IQ) {  // access-shape study schedules (cfg2 only)
+  if constexpr (K::NT == 64 && K::M == 64 && K::FMT == PFB_FMT_INT16_IQ && K::C == 8) {  // access-shape study schedules (cfg2 only)
     if (p.schedule == 2) {  // one chunk per wave, tile_waves adjacent chunks per workgroup
       if (p.tile_waves == 1) return launch_tile<K, 1>(p, s);
       return launch_tile<K, 8>(p, s);

@@ -225,7 +225,6 @@ using Cfg560x12i16 =
     FastCfg<560, 12, 560, 1, PFB_FMT_INT16_IQ, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;
 using Cfg560x12i8 =
     FastCfg<560, 12, 560, 1, PFB_FMT_INT8_IQ, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;
-
 struct FastEntry { int M, P, D, fmt; FastKernelInfo info; };
 
 template <class K>
