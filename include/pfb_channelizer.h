@@ -191,9 +191,10 @@ typedef enum pfb_option {
                                 /* 1 = persistent waves over strided chunks, 2 = one chunk per   */
                                 /* wave with adjacent chunks grouped into workgroups, 3 = short  */
                                 /* sliding runs whose halo rows are shared through LDS, 4 = 3    */
-                                /* with the FIR and the FFT on different waves (M = 64 kernels)  */
-  PFB_OPT_GRID = 7,             /* schedule 1: workgroups to launch (0 = all that are resident)  */
-  PFB_OPT_TILE_WAVES = 8,       /* schedules 2/3: waves per workgroup                           */
+                                /* with the FIR and the FFT on different waves (M = 64 kernels), */
+                                /* 5 = 4 with resident workgroups walking strided tiles (int16)  */
+  PFB_OPT_GRID = 7,             /* schedules 1/5: workgroups to launch (0 = all that are resident) */
+  PFB_OPT_TILE_WAVES = 8,       /* schedules 2/3: waves, 4/5: wave pairs per workgroup           */
   PFB_OPT_EXPERIMENT = 9,       /* bit mask of timing experiments; 0 in production               */
   PFB_OPT_VARIANT = 10          /* n-th fused kernel registered for this shape (0 = default plan) */
 } pfb_option;

@@ -805,6 +805,141 @@ struct FastKernel {
     }
   }
 
+  // ---- schedule G: persistent wave pairs ------------------------------------------------------------
+  // Schedule F's workgroups are short-lived (NPAIR * L frames, a dozen microseconds) and only one fits a CU
+  // (LDS), so every workgroup's start-up -- table loads, W-1 halo rows and the first chunk from HBM, the
+  // FFT waves idling through the first step and the FIR waves through the last -- is exposed.  Here a
+  // workgroup stays and walks tiles b, b + G, b + 2G, ...: two steps before a tile ends its FIR wave sends the
+  // NEXT tile's halo rows from HBM straight into the other of two LDS slot sets (global_load_lds, no
+  // registers), in the last step it prefetches the next tile's first chunk like any other chunk, and the FFT
+  // wave's lag of one chunk simply carries across the tile boundary.  Tiles that touch the stream's ends take the checked
+  // loads, unpipelined.
+  template <int NPAIR, int L>
+  struct PersistentPairs {
+    static constexpr int NCH = L / C, TAIL0 = L - (W - 1), SLOT = (W - 1) * D;
+    static_assert(NCH % 2 == 0, "chunk buffers alternate across tile boundaries");
+    static_assert(NT == 64 && L % C == 0 && L >= W - 1 && NCH >= 2, "one wave per run and role");
+
+    PFB_DEV bool interior(const KernelParams& p, long long tile) {
+      const long long f_blk = tile * (long long)(NPAIR * L);
+      return p.vec_ok && ((f_blk - (W - 1)) * D + p.base >= 0) && (f_blk + NPAIR * L <= p.frames);
+    }
+
+    // one tile of the FIR role.  pre: the previous tile already brought this tile's halo rows into its LDS
+    // slot (global_load_lds: HBM -> LDS without passing through registers) and its first chunk into raw[];
+    // next_pre: do the same for the next tile before leaving.
+    template <bool INTERIOR>
+    PFB_DEV void fir_tile(const KernelParams& p, const Consts& k, float2* bufs, raw_t* slots, int set, int pair, int tid,
+                          long long f_begin, long long f_next, bool pre, bool next_pre, raw_t (&raw)[C][CPT]) {
+      static_assert(CPT == 1 && sizeof(raw_t) == 4, "one dword per lane and row");
+      const int c0 = tid;
+      const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
+      raw_t* halo_mine = slots + (set * (NPAIR + 1) + pair) * SLOT;
+      const raw_t* halo_next = slots + (set * (NPAIR + 1) + pair + 1) * SLOT;
+      v2f x[NW][CPT];
+      if (!pre) {
+        raw_t h[W - 1][CPT];
+#pragma unroll
+        for (int i = 0; i < W - 1; ++i) load_row<INTERIOR>(p, run_ptr, f_begin - (W - 1) + i, i, c0, h[i]);
+#pragma unroll
+        for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + t, W - 1 + t, c0, raw[t]);
+#pragma unroll
+        for (int i = 0; i < W - 1; ++i) {
+          x[i][0] = cvt(h[i][0]);
+          if constexpr (INTERIOR) halo_mine[i * D + c0] = h[i][0];
+        }
+        __syncthreads();  // A: halo slots published
+      } else {
+#pragma unroll
+        for (int i = 0; i < W - 1; ++i) x[i][0] = cvt(halo_mine[i * D + c0]);
+      }
+      const bool tail_from_lds = INTERIOR && (pair < NPAIR - 1);
+      const raw_t* next_ptr = static_cast<const raw_t*>(p.in) + ((f_next - (W - 1)) * D + p.base);
+#pragma unroll
+      for (int ci = 0; ci < NCH; ++ci) {
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+          const int r = ci * C + t;
+          if (r >= TAIL0 && tail_from_lds) x[W - 1 + t][0] = cvt(halo_next[(r - TAIL0) * D + c0]);
+          else x[W - 1 + t][0] = cvt(raw[t][0]);
+        }
+        if (ci + 1 < NCH) {
+#pragma unroll
+          for (int t = 0; t < C; ++t) {
+            const int r = (ci + 1) * C + t;
+            if (!(r >= TAIL0 && tail_from_lds)) load_row<INTERIOR>(p, run_ptr, f_begin + r, W - 1 + r, c0, raw[t]);
+          }
+        } else if constexpr (INTERIOR) {
+          if (next_pre) {  // the next tile's first chunk, a step ahead like any other chunk
+#pragma unroll
+            for (int t = 0; t < C; ++t) load_row<true>(p, next_ptr, 0, W - 1 + t, c0, raw[t]);
+          }
+        }
+        if constexpr (INTERIOR) {
+          if (ci == NCH - 2 && next_pre) {  // the next tile's halo rows: HBM -> the other slot set, two steps ahead
+            raw_t* dst = slots + ((set ^ 1) * (NPAIR + 1) + pair) * SLOT;
+#pragma unroll
+            for (int i = 0; i < W - 1; ++i)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(next_ptr + i * D + c0),
+                                               (__attribute__((address_space(3))) void*)(dst + i * D), 4, 0, 0);
+          }
+        }
+        fir_to_lds(k, x, bufs + (ci & 1) * K::BUF, tid);
+#pragma unroll
+        for (int i = 0; i < W - 1; ++i) x[i][0] = x[i + C][0];
+        __syncthreads();  // chunk ci handed to the FFT wave (and, at the end, the next tile's halo is in place)
+      }
+    }
+
+    PFB_DEV void run(const KernelParams& p, float2* lds_fft, raw_t* slots) {
+      const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
+      const bool fir_role = wave < NPAIR;
+      const int pair = fir_role ? wave : wave - NPAIR;
+      const long long per_tile = (long long)NPAIR * L;
+      const long long ntiles = (p.frames + per_tile - 1) / per_tile, G = gridDim.x;
+      float2* bufs = lds_fft + pair * 2 * K::BUF;
+      Consts k;
+      setup(p, tid, k);
+      if (fir_role) {
+        raw_t raw[C][CPT];
+        bool pre = false;
+        int set = 0;
+        for (long long tile = blockIdx.x; tile < ntiles; tile += G, set ^= 1) {
+          const bool in = interior(p, tile);
+          const bool next_pre = in && (tile + G < ntiles) && interior(p, tile + G);
+          const long long f_begin = tile * per_tile + (long long)pair * L;
+          const long long f_next = (tile + G) * per_tile + (long long)pair * L;
+          if (in) fir_tile<true>(p, k, bufs, slots, set, pair, tid, f_begin, f_next, pre, next_pre, raw);
+          else fir_tile<false>(p, k, bufs, slots, set, pair, tid, f_begin, f_next, false, false, raw);
+          pre = next_pre;
+        }
+      } else {
+        bool pending = false, pre = false;
+        long long pend_f0 = 0;
+        int pend_buf = 0;
+        for (long long tile = blockIdx.x; tile < ntiles; tile += G) {
+          const bool in = interior(p, tile);
+          const bool next_pre = in && (tile + G < ntiles) && interior(p, tile + G);
+          const long long f_begin = tile * per_tile + (long long)pair * L;
+          if (!pre) {  // the FIR waves load this tile's first rows synchronously: transform under that
+            if (pending) { fft_from_lds(p, k, bufs + pend_buf * K::BUF, tid, pend_f0); pending = false; }
+            __syncthreads();  // A
+          }
+#pragma unroll
+          for (int ci = 0; ci < NCH; ++ci) {
+            if (pending) fft_from_lds(p, k, bufs + pend_buf * K::BUF, tid, pend_f0);
+            __syncthreads();
+            pending = true;
+            pend_f0 = f_begin + (long long)ci * C;
+            pend_buf = ci & 1;
+          }
+          pre = next_pre;
+        }
+        if (pending) fft_from_lds(p, k, bufs + pend_buf * K::BUF, tid, pend_f0);
+      }
+    }
+  };
+
   // ---- schedule B: persistent waves, strided chunks ---------------------------------------------
   // The grid is sized to what is resident at once; workgroup b handles chunks b', b'+G, b'+2G, ...
   // (b' = XCD-aware slot), so at any moment the whole chip works on ~G consecutive chunks: a compact
@@ -964,6 +1099,36 @@ hipError_t launch_paired(const KernelParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <class K, int NPAIR, int L, int MINW>
+__global__ void __launch_bounds__(128 * NPAIR, MINW) pfb_persistent_pairs_kernel(const KernelParams p) {
+  using raw_t = typename SampleT<K::FMT>::raw_t;
+  __shared__ float2 lds_fft[NPAIR * 2 * K::BUF];
+  __shared__ raw_t lds_halo[2 * (NPAIR + 1) * (K::W - 1) * K::D];
+  typename FastKernel<K>::template PersistentPairs<NPAIR, L> pp;
+  pp.run(p, lds_fft, lds_halo);
+}
+
+template <class K, int NPAIR, int L, int MINW>
+hipError_t launch_persistent_pairs(const KernelParams& p, hipStream_t s) {
+  static int resident = 0;  // workgroups resident at once on this device class
+  if (resident == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pfb_persistent_pairs_kernel<K, NPAIR, L, MINW>,
+                                                                128 * NPAIR, 0);
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    resident = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
+  }
+  const long long per = (long long)NPAIR * L;
+  const long long tiles = (p.frames + per - 1) / per;
+  long long grid = p.grid_override > 0 ? p.grid_override : resident;
+  if (grid > tiles) grid = tiles;
+  hipLaunchKernelGGL((pfb_persistent_pairs_kernel<K, NPAIR, L, MINW>), dim3((unsigned)grid), dim3(128 * NPAIR), 0, s, p);
+  return hipGetLastError();
+}
+
 template <class K, int NWV, int L>
 hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s);
 
@@ -1023,7 +1188,16 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   }
   // (measured on cfg3, cfg5 and M=56 too: slower than their sliding runs, so only the M=64 kernels carry it)
   if constexpr (K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::M == 64 && K::C == 8) {
-    if (p.schedule == 4) {  // FIR / FFT wave pairs: tile_waves = pairs per workgroup, frames_per_block = run length
+    constexpr bool kPersistentOk = K::CPT == 1 && sizeof(typename SampleT<K::FMT>::raw_t) == 4;  // dword rows (int16 I/Q)
+    if constexpr (kPersistentOk) {
+      if (p.schedule == 5) {  // persistent wave pairs
+        constexpr size_t kPairP = sizeof(float2) * 2 * K::BUF, kSlotP = sizeof(typename SampleT<K::FMT>::raw_t) * (K::W - 1) * K::D;
+        static_assert(8 * kPairP + 18 * kSlotP <= 160 * 1024, "8 pairs + two halo slot sets fit the LDS");
+        if (p.tile_waves == 4) return launch_persistent_pairs<K, 4, 64, 2>(p, s);
+        return launch_persistent_pairs<K, 8, 64, 4>(p, s);
+      }
+    }
+    if (p.schedule == 4 || p.schedule == 5) {  // FIR / FFT wave pairs: tile_waves = pairs per workgroup, frames_per_block = run length
       const int key = p.tile_waves * 1000 + p.frames_per_block;
       if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64) {  // tuning sweep set (cfg2 only, keeps build time sane)
         switch (key) {

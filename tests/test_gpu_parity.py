@@ -419,6 +419,35 @@ def test_paired_schedule_gives_identical_bits(oracle, tw, fpb):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("tw,grid,frames", [(8, 0, 7001), (8, 3, 7001), (4, 5, 20000), (8, 1, 512 * 9), (8, 0, 300000)])
+def test_persistent_pairs_schedule_gives_identical_bits(oracle, tw, grid, frames):
+    """schedule 5: the wave pairs stay resident and walk tiles b, b+G, ...; the next tile's halo rows go HBM -> LDS
+    (global_load_lds) two steps ahead.  Small grids make every workgroup cross many tile boundaries; streams that are
+    not whole tiles, calls cut mid-tile and the int8 fallback (schedule 4) must all give the sliding kernel's bits."""
+    import torch
+    M, P = 64, 12
+    n = M * frames + 3
+    iq = synth.pulsed_iq_torch(n, 12, device="cuda")
+    h = oracle.design_prototype(M, P).astype(np.float32)
+    with Channelizer(M, taps=h, bit_width=12) as ch:
+        ch.set_option(L.PFB_OPT_SCHEDULE, 0)
+        ref = ch(iq).clone()
+        ch.reset()
+        ch.set_option(L.PFB_OPT_SCHEDULE, 5)
+        ch.set_option(L.PFB_OPT_TILE_WAVES, tw)
+        ch.set_option(L.PFB_OPT_GRID, grid)
+        cut = M * (frames // 3) + 7
+        got = torch.cat([ch(iq[:cut]), ch(iq[cut:])])
+        assert torch.equal(got, ref)
+    iq8 = synth.pulsed_iq_numpy(M * 3000, 8, np.int8, seed=3)
+    with Channelizer(M, taps=h, sample_format="int8", bit_width=8) as ch:
+        ch.set_option(L.PFB_OPT_SCHEDULE, 0)
+        ref8 = ch(iq8)
+        ch.reset()
+        ch.set_option(L.PFB_OPT_SCHEDULE, 5)
+        assert np.array_equal(ch(iq8), ref8)
+
+
 def test_iq_file_front_end(oracle, tmp_path):
     """pfb_process_iq_file: record from disk -> channels, and its checks (format mismatch, truncated payload)."""
     import os
