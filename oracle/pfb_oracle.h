@@ -25,7 +25,8 @@
  * golden vectors).  The arithmetic below restates the documented polyphase
  * analysis filter bank (channel k = prototype modulated to +k*fs/M, maximally
  * decimated or D = M/2), in two independent formulations that must agree to
- * ~1e-12 (tests/test_oracle.py).  The record header / filename pieces ARE
+ * ~1e-12, and with scipy.signal.upfirdn applied per channel (tests/test_oracle.py).
+ * The record header / filename pieces ARE
  * pinned: oracle/_ref builds the reference's own IqPacket.h / Helper.cpp and
  * tests compare against it.
  *

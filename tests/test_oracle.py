@@ -207,3 +207,26 @@ def test_raw_pdw_extraction_known_answer(oracle):
     # with the trailing threshold raised to the leading one the dip splits the first pulse
     split, _ = oracle.extract_pdws_raw(x, fs, fc, t0, snr_db=18.0, trail_db=18.0)
     assert len(split) == 3
+
+
+@pytest.mark.parametrize("M,P,D", [(8, 12, 8), (64, 12, 64), (128, 12, 64), (56, 12, 56), (12, 5, 4)])
+def test_against_scipy_polyphase_decimator(oracle, M, P, D):
+    """An implementation nobody here wrote: scipy.signal.upfirdn (polyphase FIR + decimate, SciPy's C code) applied per
+    channel to the band-pass filter h[n] e^{+j 2 pi k n / M}.  With input_offset = D-1 frame m of channel k is sample
+    m*D + D-1 of the full-rate convolution, i.e. upfirdn(..., down=D) after dropping the first D-1 outputs.  This does
+    not pin dsp.Channelizer (nothing available can), but it does pin the FIR / decimation indexing of the oracle to a
+    third-party library."""
+    from scipy.signal import upfirdn
+    rng = np.random.default_rng(M + P + D)
+    n = D * 50
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    h = rng.standard_normal(M * P)
+    got = oracle.channelize(x, h, OracleConfig(M, P, D), "polyphase")
+    want = np.empty_like(got)
+    nn = np.arange(M * P)
+    for k in range(M):
+        hk = h * np.exp(2j * np.pi * k * nn / M)
+        full = upfirdn(hk, x, up=1, down=1)            # full-rate convolution, full[i] = sum_n hk[n] x[i-n]
+        want[:, k] = full[D - 1:n:D]
+    assert got.shape == want.shape == (n // D, M)
+    assert rel(got, want) < 1e-12
