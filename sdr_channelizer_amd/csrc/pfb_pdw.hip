@@ -700,6 +700,31 @@ struct RawSrc {
       return dkey(mag2_of(static_cast<const float2*>(p)[i]));
     }
   }
+  // keys of samples 4q .. 4q+3 from one 16-byte (int16), 8-byte (int8) or two 16-byte (cf32) loads; p 16-byte aligned
+  __device__ __forceinline__ void key4(long long q, unsigned long long (&k)[4]) const {
+    if constexpr (FMT == PFB_FMT_INT8_IQ) {
+      const int2 w = static_cast<const int2*>(p)[q];
+      const int v[2] = {w.x, w.y};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int half = (v[j >> 1] >> (16 * (j & 1))) & 0xffff;
+        const int re = (int)(signed char)(half & 0xff), im = (int)(signed char)(half >> 8);
+        k[j] = (unsigned long long)(re * re + im * im);
+      }
+    } else if constexpr (FMT == PFB_FMT_INT16_IQ) {
+      const int4 w = static_cast<const int4*>(p)[q];
+      const int v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long re = (short)(v[j] & 0xffff), im = (short)(v[j] >> 16);
+        k[j] = (unsigned long long)(re * re + im * im);
+      }
+    } else {
+      const float4 a = static_cast<const float4*>(p)[2 * q], b = static_cast<const float4*>(p)[2 * q + 1];
+      k[0] = dkey(mag2_of(make_float2(a.x, a.y))); k[1] = dkey(mag2_of(make_float2(a.z, a.w)));
+      k[2] = dkey(mag2_of(make_float2(b.x, b.y))); k[3] = dkey(mag2_of(make_float2(b.z, b.w)));
+    }
+  }
   __device__ __forceinline__ double key_mag(unsigned long long k) const {
     if constexpr (FMT == PFB_FMT_CF32) return sqrt(dkey_inv(k));
     else return sqrt((double)k) * inv_scale;
@@ -805,7 +830,7 @@ constexpr int kRawBits = 11, kRawBins = 1 << kRawBits;
 
 // one digit pass of the radix select of the stream's median |x|^2 key: digit = (key >> shift) & (bins-1)
 // among keys whose bits above the digit equal `prefix`
-template <class Src>
+template <class Src, bool VEC>
 __global__ void __launch_bounds__(256) pdw_raw_hist_kernel(Src src, long long n, int shift, unsigned bins_mask,
                                                            unsigned long long prefix, unsigned long long prefix_mask,
                                                            unsigned* hist) {
@@ -813,14 +838,20 @@ __global__ void __launch_bounds__(256) pdw_raw_hist_kernel(Src src, long long n,
   for (int i = threadIdx.x; i < kRawBins; i += 256) h[i] = 0u;
   __syncthreads();
   const long long step = (long long)gridDim.x * 1024;
-  for (long long i0 = (long long)blockIdx.x * 1024; i0 < n; i0 += step) {  // four loads in flight per thread
+  for (long long i0 = (long long)blockIdx.x * 1024; i0 < n; i0 += step) {  // four samples per thread in flight
     unsigned long long k[4];
     bool in[4];
+    if (VEC && i0 + 1024 <= n) {  // one wide load: samples i0 + 4 tid .. + 3
+      src.key4((i0 >> 2) + threadIdx.x, k);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long long i = i0 + u * 256 + threadIdx.x;
-      in[u] = i < n;
-      k[u] = in[u] ? src.key(i) : 0ull;
+      for (int u = 0; u < 4; ++u) in[u] = true;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long i = i0 + u * 256 + threadIdx.x;
+        in[u] = i < n;
+        k[u] = in[u] ? src.key(i) : 0ull;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) hist_add(h, (unsigned)(k[u] >> shift) & bins_mask, in[u] && ((k[u] & prefix_mask) == prefix));
@@ -831,16 +862,23 @@ __global__ void __launch_bounds__(256) pdw_raw_hist_kernel(Src src, long long n,
 }
 
 // number of keys below `pivot` and the largest of them (the lower middle value of an even-length median)
-template <class Src>
+template <class Src, bool VEC>
 __global__ void __launch_bounds__(256) pdw_raw_below_kernel(Src src, long long n, unsigned long long pivot,
                                                             unsigned long long* below, unsigned long long* max_below) {
   unsigned long long nb = 0ull, best = 0ull;
   bool any = false;
   const long long step = (long long)gridDim.x * 1024;
-  for (long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += step) {  // four loads in flight
+  for (long long i0 = (long long)blockIdx.x * 1024; i0 < n; i0 += step) {  // four samples per thread in flight
     unsigned long long k[4];
+    if (VEC && i0 + 1024 <= n) {
+      src.key4((i0 >> 2) + threadIdx.x, k);
+    } else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) k[u] = (i0 + u * 256 < n) ? src.key(i0 + u * 256) : ~0ull;
+      for (int u = 0; u < 4; ++u) {
+        const long long i = i0 + u * 256 + threadIdx.x;
+        k[u] = (i < n) ? src.key(i) : ~0ull;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (k[u] < pivot) { ++nb; best = (any && best > k[u]) ? best : k[u]; any = true; }
@@ -857,10 +895,10 @@ __global__ void __launch_bounds__(256) pdw_raw_mask_kernel(Src src, long long n,
   const long long w0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
   if (w0 >= words) return;
   unsigned long long a = 0ull, b = 0ull;
-  for (int i0 = 0; i0 < 64; i0 += 8) {  // eight loads in flight per lane
-    bool ge[8], gt[8];
+  for (int i0 = 0; i0 < 64; i0 += 16) {  // sixteen loads in flight per lane
+    bool ge[16], gt[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const long long sidx = (w0 + i0 + u) * 64 + lane;
       ge[u] = false; gt[u] = true;  // past the end: identity
       if (sidx < n) {
@@ -870,7 +908,7 @@ __global__ void __launch_bounds__(256) pdw_raw_mask_kernel(Src src, long long n,
       }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const unsigned long long wa = __ballot(ge[u]), wb = __ballot(gt[u]);
       if (lane == i0 + u) { a = wa; b = wb; }
     }
@@ -1258,6 +1296,7 @@ int extract_raw(const void* d_iq, long long n, double inv_scale, double fs, doub
                 long long ntiles, int tile_words, hipStream_t st) {
   int rc = PFB_OK;
   const RawSrc<FMT> src{d_iq, inv_scale};
+  const bool vec = (reinterpret_cast<uintptr_t>(d_iq) % 16) == 0;  // wide loads in the counting passes
   (void)ws;
   // ---- noise floor (:44): radix select of rank n/2 on the |x|^2 keys, 11-bit digits
   struct Pass { int shift, bits; };
@@ -1273,8 +1312,13 @@ int extract_raw(const void* d_iq, long long n, double inv_scale, double fs, doub
     const int top = pass[ps].shift + pass[ps].bits;
     const unsigned long long pmask = top >= 64 ? 0ull : (~0ull << top);
     PDW_TRY(hipMemsetAsync(d_hist, 0, kRawBins * sizeof(unsigned), st));
-    hipLaunchKernelGGL(pdw_raw_hist_kernel<RawSrc<FMT>>, dim3(grid), dim3(256), 0, st, src, n, pass[ps].shift,
-                       (1u << pass[ps].bits) - 1u, prefix, pmask, d_hist);
+    if (vec) {
+      hipLaunchKernelGGL((pdw_raw_hist_kernel<RawSrc<FMT>, true>), dim3(grid), dim3(256), 0, st, src, n, pass[ps].shift,
+                         (1u << pass[ps].bits) - 1u, prefix, pmask, d_hist);
+    } else {
+      hipLaunchKernelGGL((pdw_raw_hist_kernel<RawSrc<FMT>, false>), dim3(grid), dim3(256), 0, st, src, n, pass[ps].shift,
+                         (1u << pass[ps].bits) - 1u, prefix, pmask, d_hist);
+    }
     PDW_TRY(hipGetLastError());
     PDW_TRY(hipMemcpyAsync(h_hist.data(), d_hist, kRawBins * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     PDW_TRY(hipStreamSynchronize(st));
@@ -1295,7 +1339,13 @@ int extract_raw(const void* d_iq, long long n, double inv_scale, double fs, doub
     unsigned long long v0 = prefix;
     if ((n & 1) == 0) {  // even count: the lower middle value is the largest key below, unless the pivot repeats
       PDW_TRY(hipMemsetAsync(d_pair, 0, 2 * sizeof(unsigned long long), st));
-      hipLaunchKernelGGL(pdw_raw_below_kernel<RawSrc<FMT>>, dim3(grid), dim3(256), 0, st, src, n, prefix, d_pair, d_pair + 1);
+      if (vec) {
+        hipLaunchKernelGGL((pdw_raw_below_kernel<RawSrc<FMT>, true>), dim3(grid), dim3(256), 0, st, src, n, prefix, d_pair,
+                           d_pair + 1);
+      } else {
+        hipLaunchKernelGGL((pdw_raw_below_kernel<RawSrc<FMT>, false>), dim3(grid), dim3(256), 0, st, src, n, prefix, d_pair,
+                           d_pair + 1);
+      }
       PDW_TRY(hipGetLastError());
       PDW_TRY(hipMemcpyAsync(h_pair, d_pair, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
       PDW_TRY(hipStreamSynchronize(st));

@@ -178,6 +178,17 @@ def test_raw_stream_cf32_device_input_and_custom_thresholds(oracle):
     compare(got, want, 8e6)
 
 
+def test_raw_stream_misaligned_device_buffer(oracle):
+    """a device pointer that is not 16-byte aligned takes the narrow loads; same PDWs"""
+    import torch
+    iq, x = raw_stream(60000, np.int16, 12, seed=11)
+    d = torch.from_numpy(iq).cuda()
+    got = extract_pdws_raw(d[3:], 56e6, 0.0, 0.0)
+    want, _ = oracle.extract_pdws_raw(x[3:], 56e6, 0.0, 0.0)
+    assert len(want) >= 6
+    compare(got, want, 56e6)
+
+
 def test_raw_stream_at_recorder_size(oracle):
     """2^24 samples on the device (a 0.3 s dwell at 56 Msps): pulse train of synth.pulsed_iq_torch.  Its pulses stand
     14 dB (the script's dB/10 convention) above the noise floor, so the leading threshold is set to 12 dB."""
