@@ -614,6 +614,144 @@ struct FastKernel {
     else run_impl<false>(p, k, lds, f_begin, f_end);
   }
 
+  // ---- schedule T: FIR team + FFT team (large M) --------------------------------------------------------
+  // At M = 1024 one frame needs all 1024 columns, so the FIR is a team effort (NT threads x CPT columns), and
+  // in the plain sliding kernel the same 16 waves then all turn to the FFT: every phase leaves either the VALU
+  // or the LDS idle, and the passes cost several workgroup barriers per chunk (44 % VALU-busy, waves waiting
+  // 63 % of their cycles: profiles/).  Here the FIR team only filters -- a sliding register window per thread,
+  // chunk after chunk into one of three LDS buffers -- and C more waves transform: FFT wave w takes frame w of
+  // the previous chunk and runs the first two passes of its M-point FFT alone (M / 64 points per lane), so
+  // those passes need no barrier at all, only the wave's own program order.  One workgroup barrier per chunk
+  // rotates the buffers.
+  template <int I>
+  PFB_DEV void pass_frame(const KernelParams& p, float2* fbuf, int lane, long long f, const v2f (&tw)[2][16]) {
+    constexpr int R = K::R(I), S = K::S(I), KK = K::K(I), RS = K::RS(I);
+    constexpr int IPF = M / R, ITERS = IPF / 64;
+    constexpr bool LAST = (I == K::NP - 1);
+    static_assert(IPF % 64 == 0 && (LAST || ITERS == 1), "whole waves; in place needs every read before any write");
+    static_assert(K::POW2 && OS == 1, "power-of-two, critically sampled shapes");
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int item = lane + it * 64;
+      const int kk = item / S, rest = item % S;
+      v2f x[R];
+      const v2f* s2 = reinterpret_cast<const v2f*>(fbuf) + item;
+#pragma unroll
+      for (int n = 0; n < R; ++n) x[n] = s2[n * RS];
+      Dft<R>::run(x);
+      if constexpr (!LAST) {
+        constexpr int S1 = K::S(I + 1), RS1 = K::RS(I + 1);
+#pragma unroll
+        for (int k = 1; k < R; ++k) x[k] = cmul_w(x[k], tw[I][k]);
+        const int n1 = rest / S1, rest2 = rest % S1;
+        v2f* d2 = reinterpret_cast<v2f*>(fbuf) + n1 * RS1 + kk * S1 + rest2;
+#pragma unroll
+        for (int k = 0; k < R; ++k) d2[k * KK * S1] = x[k];
+      } else if (f < p.frames) {
+        const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
+        if (p.flags & PFB_FLAG_MAGNITUDE) {
+          float* row = reinterpret_cast<float*>(p.out) + f * M;
+          float* lo = row + kk + shift;
+          float* hi = row + kk + (M / 2 - shift);
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            *((k < R / 2) ? lo + k * KK : hi + (k - R / 2) * KK) = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
+        } else {
+          float2* row = p.out + f * M;
+          float2* lo = row + kk + shift;
+          float2* hi = row + kk + (M / 2 - shift);
+#pragma unroll
+          for (int k = 0; k < R; ++k) store_c64((k < R / 2) ? lo + k * KK : hi + (k - R / 2) * KK, x[k], p.nontemporal);
+        }
+      }
+    }
+  }
+
+  // FIR team: chunk ci into buffer ci % 3, then the LAST pass (and the stores) of chunk ci - 2, whose first two
+  // passes the FFT team finished in the step before.  The stores are most of the FFT's memory work and the FIR
+  // team has issue slots to spare, while four FFT waves doing everything were the bottleneck (2.4 of 2.9 ms).
+  template <bool INTERIOR>
+  PFB_DEV void fir_team(const KernelParams& p, const Consts& k, float2* bufs, long long f_begin, int nch) {
+    const int tid = threadIdx.x;
+    const int c0 = tid * CPT;
+    const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
+    v2f x[NW][CPT];
+    raw_t raw[2][C][CPT];  // two chunks of rows in flight: one chunk is only ~1.5 us of work, less than a loaded HBM round trip
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) {
+      raw_t t[CPT];
+      load_row<INTERIOR>(p, run_ptr, f_begin - (W - 1) + i, i, c0, t);
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(t[cc]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + u * C + t, W - 1 + u * C + t, c0, raw[u][t]);
+    int b_fir = 0, b_last = 1;  // buffer of chunk ci, buffer of chunk ci - 2 (= (ci + 1) % 3)
+    for (int ci2 = 0; ci2 < nch; ci2 += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ci = ci2 + u;
+        const long long f0 = f_begin + (long long)ci * C;
+#pragma unroll
+        for (int t = 0; t < C; ++t)
+#pragma unroll
+          for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[u][t][cc]);
+        if (ci + 2 < nch) {
+          const long long rel = (long long)(ci + 2) * C + (W - 1);
+#pragma unroll
+          for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f0 + 2 * C + t, rel + t, c0, raw[u][t]);
+        }
+        fir_to_lds(k, x, bufs + b_fir * K::BUF, tid);
+#pragma unroll
+        for (int i = 0; i < W - 1; ++i)
+#pragma unroll
+          for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
+        if (ci >= 2) pass<K::NP - 1>(p, bufs + b_last * K::BUF, nullptr, tid, f0 - 2 * C, k.tw);
+        __syncthreads();  // chunk ci handed to the FFT team, buffer of chunk ci - 2 free again
+        b_fir = (b_fir == 2) ? 0 : b_fir + 1;
+        b_last = (b_last == 2) ? 0 : b_last + 1;
+      }
+    }
+    // drain: the FFT team finishes chunk nch - 1 while chunk nch - 2 gets its last pass, then chunk nch - 1
+    if (nch >= 2) pass<K::NP - 1>(p, bufs + b_last * K::BUF, nullptr, tid, f_begin + (long long)(nch - 2) * C, k.tw);
+    __syncthreads();
+    b_last = (b_last == 2) ? 0 : b_last + 1;
+    pass<K::NP - 1>(p, bufs + b_last * K::BUF, nullptr, tid, f_begin + (long long)(nch - 1) * C, k.tw);
+  }
+
+  PFB_DEV void run_teams(const KernelParams& p, float2* bufs) {
+    static_assert(K::NP == 3 && !K::PINGPONG && !K::TW_TABLE && NT % 64 == 0, "three in-place passes, twiddles in registers");
+    const long long f_begin = (long long)blockIdx.x * p.frames_per_block;
+    if (f_begin >= p.frames) return;
+    const int nch = p.frames_per_block / C;  // even (host rounds); the last workgroup filters zero padding past the end
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < NT / 64) {
+      Consts k;
+      setup(p, threadIdx.x, k);
+      const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_begin + p.frames_per_block <= p.frames);
+      if (interior) fir_team<true>(p, k, bufs, f_begin, nch);
+      else fir_team<false>(p, k, bufs, f_begin, nch);
+    } else {
+      const int fr = wave - NT / 64;  // my frame inside every chunk
+      Consts k;
+      setup(p, lane, k);  // only the twiddles are used: rows `lane % S` of the passes' tables
+      int b = 0;          // buffer of chunk s - 1
+#pragma unroll 1
+      for (int s = 0; s <= nch; ++s) {
+        if (s >= 1) {
+          float2* fbuf = bufs + b * K::BUF + fr * K::FS;
+          pass_frame<0>(p, fbuf, lane, 0, k.tw);
+          team_sync<true>();
+          pass_frame<1>(p, fbuf, lane, 0, k.tw);
+          b = (b == 2) ? 0 : b + 1;
+        }
+        __syncthreads();
+      }
+    }
+  }
+
   // ---- schedule D: sliding windows with the halo shared inside the workgroup -------------------------
   // A workgroup of NWV waves covers NWV*L consecutive frames, wave w the L frames [w*L, (w+1)*L) with its
   // own register window.  Short runs keep the whole chip inside one dense, in-order sweeping window
@@ -1129,6 +1267,12 @@ hipError_t launch_persistent_pairs(const KernelParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <class K>
+__global__ void __launch_bounds__(K::NT + 64 * K::C, K::MIN_WAVES) pfb_teams_kernel(const KernelParams p) {
+  __shared__ float2 bufs[3 * K::BUF];
+  FastKernel<K>::run_teams(p, bufs);
+}
+
 template <class K, int NWV, int L>
 hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s);
 
@@ -1187,6 +1331,13 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
     }
   }
   // (measured on cfg3, cfg5 and M=56 too: slower than their sliding runs, so only the M=64 kernels carry it)
+  if constexpr (K::NP == 3 && !K::PINGPONG && !K::TW_TABLE && K::NT > 64 && K::POW2) {  // FIR team + FFT team
+    if (p.schedule == 6) {
+      const long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
+      hipLaunchKernelGGL(pfb_teams_kernel<K>, dim3((unsigned)nb), dim3(K::NT + 64 * K::C), 0, s, p);
+      return hipGetLastError();
+    }
+  }
   if constexpr (K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::M == 64 && K::C == 8) {
     constexpr bool kPersistentOk = K::CPT == 1 && sizeof(typename SampleT<K::FMT>::raw_t) == 4;  // dword rows (int16 I/Q)
     if constexpr (kPersistentOk) {

@@ -224,7 +224,13 @@ using Cfg56x12i8  = FastCfg<56, 12, 56, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 7, 1, 7, 9
 using Cfg560x12i16 =
     FastCfg<560, 12, 560, 1, PFB_FMT_INT16_IQ, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;
 using Cfg560x12i8 =
-    FastCfg<560, 12, 560, 1, PFB_FMT_INT8_IQ, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;
+    FastCfg<560, 12, 560, 1, PFB_FMT_INT8_IQ, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;// cfg4, team plan (the default): 512 FIR threads x 2 columns filter chunks of 4 frames and run the last pass
+// + stores of the chunk before the previous one; 4 FFT waves take one frame each for the first two passes
+// (16 x 16 x 4, wave-local, twiddles in registers); 12 waves per workgroup, three LDS chunk buffers, one
+// workgroup barrier per chunk (pfb_fast.hpp, schedule T)
+using Cfg1024x16i16t =
+    FastCfg<1024, 16, 1024, 2, PFB_FMT_INT16_IQ, 4, 3, 16, 16, 4, 64, 68, 260, 1088, false, 3, false>;
+
 struct FastEntry { int M, P, D, fmt; FastKernelInfo info; };
 
 template <class K>
@@ -241,7 +247,8 @@ static const FastEntry kFastTable[] = {
     entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 512, 0),
     entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 256, 0),
     entry<Cfg256x8i16>("pfb_fast<M256,P8,D256,int16>", 256, 0),
-    entry<Cfg1024x16i16b>("pfb_fast<M1024,P16,D1024,int16>", 256, 0),
+    entry<Cfg1024x16i16t>("pfb_fast<M1024,P16,D1024,int16>", 512, 6),
+    entry<Cfg1024x16i16b>("pfb_fast<M1024,P16,D1024,int16,16w>", 256, 0),
     entry<Cfg1024x16i16>("pfb_fast<M1024,P16,D1024,int16,8w>", 256, 0),
     entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 0),
     entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 0),
