@@ -213,6 +213,14 @@ const char* pfb_last_kernel(const pfb_handle* h);
  * roofline.  Uses `bytes_in` of input and 2*bytes_in of output scratch. */
 int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double* bytes_per_sec);
 
+/* Page-locked host memory for the sample and output buffers of PFB_MEM_HOST calls -- what the
+ * recorders would use in place of `new std::complex<std::int16_t>[n]`
+ * (cpp/blade_record_iq_12bit.cpp:268).  The host path copies chunk i+1 in while chunk i is
+ * transformed and chunk i-1 is copied out; only page-locked buffers let the two PCIe directions
+ * really overlap (pageable memory works, at the rate of the runtime's own staging).  NULL on failure. */
+void* pfb_host_alloc(size_t bytes);
+void pfb_host_free(void* p);
+
 /* ---- channelized PDW extraction ------------------------------------------------
  * Replaces the second half of matlab/create_pdws_channelized.m (lines 64-143): per-channel
  * noise floor = median magnitude (:73), threshold NF*10^(SNR_THRESHOLD/10) (:74-75), the

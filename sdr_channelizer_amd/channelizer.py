@@ -34,6 +34,22 @@ def design_prototype(num_bands: int, taps_per_band: int = 12, stopband_atten: fl
     return h
 
 
+def pinned_empty(shape, dtype):
+    """numpy array in page-locked host memory (pfb_host_alloc): buffers like this let the host path overlap the two
+    PCIe directions.  The memory is released when the array (and every view of it) is garbage-collected."""
+    import weakref
+    lib = L.load()
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape))
+    nbytes = max(1, count * dt.itemsize)
+    ptr = lib.pfb_host_alloc(nbytes)
+    if not ptr:
+        raise MemoryError(f"pfb_host_alloc({nbytes}) failed")
+    buf = (C.c_char * nbytes).from_address(ptr)
+    weakref.finalize(buf, lib.pfb_host_free, C.c_void_p(ptr))
+    return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+
+
 def center_frequencies(num_bands: int, fs: float) -> np.ndarray:
     out = np.empty(num_bands, dtype=np.float64)
     L.check(L.load().pfb_center_frequencies(num_bands, fs, out.ctypes.data_as(C.POINTER(C.c_double))),

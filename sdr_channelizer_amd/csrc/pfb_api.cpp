@@ -87,10 +87,14 @@ struct pfb_handle {
   int opt_grid = 0;
   int opt_tile_waves = 8;
   const char* last_kernel = "";
-  // host staging
-  void* d_stage_in = nullptr;
+  // host staging: two sets, so chunk i+1 crosses PCIe inbound while chunk i is transformed and chunk i-1 goes out
+  void* d_stage_in = nullptr;   // set 0 (also pfb_prime's scratch)
   void* d_stage_out = nullptr;
+  void* d_stage_in2 = nullptr;  // set 1
+  void* d_stage_out2 = nullptr;
   size_t stage_in_bytes = 0, stage_out_bytes = 0;
+  hipStream_t s_in = nullptr, s_out = nullptr;  // copy streams of the host path
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
   // PFB_OPT_PROFILE: event pairs around each channelizer kernel launch
   int opt_profile = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // reusable pairs
@@ -110,6 +114,15 @@ void free_handle(pfb_handle* h) {
   (void)hipFree(h->d_hist[1]);
   (void)hipFree(h->d_stage_in);
   (void)hipFree(h->d_stage_out);
+  (void)hipFree(h->d_stage_in2);
+  (void)hipFree(h->d_stage_out2);
+  if (h->s_in) (void)hipStreamDestroy(h->s_in);
+  if (h->s_out) (void)hipStreamDestroy(h->s_out);
+  for (int i = 0; i < 2; ++i) {
+    if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]);
+    if (h->ev_k[i]) (void)hipEventDestroy(h->ev_k[i]);
+    if (h->ev_out[i]) (void)hipEventDestroy(h->ev_out[i]);
+  }
   for (auto& pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   delete h;
 }
@@ -191,56 +204,90 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
   return PFB_OK;
 }
 
-int ensure_stage(pfb_handle* h, size_t in_bytes, size_t out_bytes) {
-  if (in_bytes > h->stage_in_bytes) {
+int ensure_stage(pfb_handle* h, size_t in_bytes, size_t out_bytes, bool both_sets = false) {
+  if (in_bytes > h->stage_in_bytes || (both_sets && in_bytes > 0 && !h->d_stage_in2)) {
+    const size_t nb = std::max(in_bytes, h->stage_in_bytes);
     (void)hipFree(h->d_stage_in);
-    h->d_stage_in = nullptr; h->stage_in_bytes = 0;
-    HIP_TRY(hipMalloc(&h->d_stage_in, in_bytes));
-    h->stage_in_bytes = in_bytes;
+    (void)hipFree(h->d_stage_in2);
+    h->d_stage_in = h->d_stage_in2 = nullptr; h->stage_in_bytes = 0;
+    HIP_TRY(hipMalloc(&h->d_stage_in, nb));
+    if (both_sets) HIP_TRY(hipMalloc(&h->d_stage_in2, nb));
+    h->stage_in_bytes = nb;
   }
-  if (out_bytes > h->stage_out_bytes) {
+  if (out_bytes > h->stage_out_bytes || (both_sets && out_bytes > 0 && !h->d_stage_out2)) {
+    const size_t nb = std::max(out_bytes, h->stage_out_bytes);
     (void)hipFree(h->d_stage_out);
-    h->d_stage_out = nullptr; h->stage_out_bytes = 0;
-    HIP_TRY(hipMalloc(&h->d_stage_out, out_bytes));
-    h->stage_out_bytes = out_bytes;
+    (void)hipFree(h->d_stage_out2);
+    h->d_stage_out = h->d_stage_out2 = nullptr; h->stage_out_bytes = 0;
+    HIP_TRY(hipMalloc(&h->d_stage_out, nb));
+    if (both_sets) HIP_TRY(hipMalloc(&h->d_stage_out2, nb));
+    h->stage_out_bytes = nb;
   }
   return PFB_OK;
 }
 
 int process_host(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t frames_total) {
   // Stage through device buffers in chunks (multiples of D so chunks never change the carried phase
-  // pattern mid-call beyond what the stream semantics already define).
+  // pattern mid-call beyond what the stream semantics already define).  Three streams and two buffer
+  // sets: chunk i+1 is copied in while chunk i is transformed and chunk i-1 is copied out, so a caller
+  // whose buffers are page-locked (pfb_host_alloc) sees both PCIe directions busy at once; with pageable
+  // memory the runtime's own staging serialises the copies and this degrades to the plain sequence.
   uint64_t chunk = h->opt_host_chunk > 0 ? (uint64_t)h->opt_host_chunk : (uint64_t)1 << 24;
   chunk = ((chunk + h->D - 1) / h->D) * h->D;
   const uint64_t max_frames = chunk / h->D + 1;
   const int rc = ensure_stage(h, (size_t)std::min<uint64_t>(chunk, n ? n : 1) * h->bps,
                               (size_t)std::min<uint64_t>(max_frames, frames_total ? frames_total : 1) * h->M *
-                                  sizeof(float2));
+                                  sizeof(float2), true);
   if (rc != PFB_OK) return rc;
+  if (!h->s_in) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_k[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_out[i], hipEventDisableTiming));
+    }
+  }
+  void* const st_in[2] = {h->d_stage_in, h->d_stage_in2};
+  void* const st_out[2] = {h->d_stage_out, h->d_stage_out2};
   const char* src = static_cast<const char*>(iq);
   char* dst = static_cast<char*>(out);
   uint64_t done = 0, frames_done = 0;
-  while (done < n) {
+  // whatever the caller queued on the handle's stream comes first
+  HIP_TRY(hipEventRecord(h->ev_k[1], h->stream));
+  HIP_TRY(hipStreamWaitEvent(h->s_in, h->ev_k[1], 0));
+  int rc2 = PFB_OK;
+  for (uint64_t i = 0; done < n; ++i) {
+    const int b = (int)(i & 1);
     const uint64_t m = std::min<uint64_t>(chunk, n - done);
     const uint64_t f = frames_for(h, m);
-    HIP_TRY(hipMemcpyAsync(h->d_stage_in, src + done * h->bps, (size_t)m * h->bps, hipMemcpyHostToDevice, h->stream));
-    const int rc2 = enqueue(h, h->d_stage_in, m, h->d_stage_out, f, (int64_t)f, 0);
-    if (rc2 != PFB_OK) return rc2;
+    if (i >= 2) HIP_TRY(hipStreamWaitEvent(h->s_in, h->ev_k[b], 0));  // the kernel of chunk i-2 has read this input buffer
+    HIP_TRY(hipMemcpyAsync(st_in[b], src + done * h->bps, (size_t)m * h->bps, hipMemcpyHostToDevice, h->s_in));
+    HIP_TRY(hipEventRecord(h->ev_in[b], h->s_in));
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_in[b], 0));
+    if (i >= 2) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out[b], 0));  // chunk i-2 has left this output buffer
+    rc2 = enqueue(h, st_in[b], m, st_out[b], f, (int64_t)f, 0);
+    if (rc2 != PFB_OK) break;
+    HIP_TRY(hipEventRecord(h->ev_k[b], h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->s_out, h->ev_k[b], 0));
     if (f > 0) {
       if (h->layout == PFB_LAYOUT_FRAME_MAJOR) {
-        HIP_TRY(hipMemcpyAsync(dst + frames_done * h->M * h->out_elem, h->d_stage_out,
-                               (size_t)f * h->M * h->out_elem, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(dst + frames_done * h->M * h->out_elem, st_out[b], (size_t)f * h->M * h->out_elem,
+                               hipMemcpyDeviceToHost, h->s_out));
       } else {  // column k of this chunk -> rows [frames_done, frames_done+f) of column k of the call
-        HIP_TRY(hipMemcpy2DAsync(dst + frames_done * h->out_elem, (size_t)frames_total * h->out_elem,
-                                 h->d_stage_out, (size_t)f * h->out_elem, (size_t)f * h->out_elem,
-                                 (size_t)h->M, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpy2DAsync(dst + frames_done * h->out_elem, (size_t)frames_total * h->out_elem, st_out[b],
+                                 (size_t)f * h->out_elem, (size_t)f * h->out_elem, (size_t)h->M, hipMemcpyDeviceToHost,
+                                 h->s_out));
       }
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));  // staging buffers are reused by the next chunk
+    HIP_TRY(hipEventRecord(h->ev_out[b], h->s_out));
     done += m;
     frames_done += f;
   }
-  return PFB_OK;
+  HIP_TRY(hipStreamSynchronize(h->s_in));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipStreamSynchronize(h->s_out));
+  return rc2;
 }
 
 }  // namespace
@@ -649,6 +696,19 @@ int pfb_get_kernel_times(pfb_handle* h, float* ms_out, int capacity, int* count)
   h->ev_used = 0;
   *count = n;
   return PFB_OK;
+}
+
+void* pfb_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void pfb_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double* bytes_per_sec) {

@@ -448,6 +448,29 @@ def test_persistent_pairs_schedule_gives_identical_bits(oracle, tw, grid, frames
         assert np.array_equal(ch(iq8), ref8)
 
 
+def test_page_locked_host_buffers_and_pipelined_staging():
+    """pfb_host_alloc buffers through the host path: five staging chunks in flight over three streams give the bits of
+    one device-resident call, in both layouts"""
+    import torch
+    from sdr_channelizer_amd import pinned_empty
+    M, P = 64, 12
+    n = M * 9000 + 21
+    iq = synth.pulsed_iq_numpy(n, 12, np.int16, seed=13)
+    h = np.random.default_rng(3).standard_normal(M * P).astype(np.float32) / M
+    iq_p = pinned_empty(iq.shape, iq.dtype)
+    iq_p[:] = iq
+    for cm in (False, True):
+        with Channelizer(M, taps=h, bit_width=12, channel_major=cm) as ch:
+            ref = ch(torch.from_numpy(iq).cuda()).cpu().numpy()
+            ch.reset()
+            ch.set_option(L.PFB_OPT_HOST_CHUNK_SAMPLES, M * 2000)
+            out_p = pinned_empty(ref.shape, ref.dtype)
+            got = ch(iq_p, out=out_p)
+            assert np.array_equal(got, ref)
+            ch.reset()
+            assert np.array_equal(ch(iq), ref)   # pageable memory, same pipeline
+
+
 def test_iq_file_front_end(oracle, tmp_path):
     """pfb_process_iq_file: record from disk -> channels, and its checks (format mismatch, truncated payload)."""
     import os
