@@ -623,46 +623,47 @@ struct FastKernel {
   // the previous chunk and runs the first two passes of its M-point FFT alone (M / 64 points per lane), so
   // those passes need no barrier at all, only the wave's own program order.  One workgroup barrier per chunk
   // rotates the buffers.
+  // One non-final pass of ONE frame by one wave, in place: every read of the pass (all iterations) happens
+  // before its first write, and the wave's own program order is the only synchronisation.
   template <int I>
-  PFB_DEV void pass_frame(const KernelParams& p, float2* fbuf, int lane, long long f, const v2f (&tw)[2][16]) {
+  PFB_DEV void pass_frame(const KernelParams& p, float2* fbuf, int lane, const v2f (&tw)[2][16]) {
     constexpr int R = K::R(I), S = K::S(I), KK = K::K(I), RS = K::RS(I);
-    constexpr int IPF = M / R, ITERS = IPF / 64;
-    constexpr bool LAST = (I == K::NP - 1);
-    static_assert(IPF % 64 == 0 && (LAST || ITERS == 1), "whole waves; in place needs every read before any write");
-    static_assert(K::POW2 && OS == 1, "power-of-two, critically sampled shapes");
+    constexpr int IPF = M / R, ITERS = (IPF + 63) / 64;
+    constexpr int S1 = K::S(I + 1), RS1 = K::RS(I + 1);
+    static_assert(I < K::NP - 1, "the last pass (with the stores) belongs to the FIR team");
+    constexpr bool TW_REGS = (ITERS == 1) && !K::TW_TABLE;
+    v2f x[ITERS][R];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int item = lane + it * 64;
+      const bool active = (IPF % 64 == 0) || (item < IPF);
+      const v2f* s2 = reinterpret_cast<const v2f*>(fbuf) + (active ? item : 0);
+#pragma unroll
+      for (int n = 0; n < R; ++n) x[it][n] = s2[n * RS];
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int item = lane + it * 64;
+      const bool active = (IPF % 64 == 0) || (item < IPF);
       const int kk = item / S, rest = item % S;
-      v2f x[R];
-      const v2f* s2 = reinterpret_cast<const v2f*>(fbuf) + item;
+      Dft<R>::run(x[it]);
+      if constexpr (TW_REGS) {
 #pragma unroll
-      for (int n = 0; n < R; ++n) x[n] = s2[n * RS];
-      Dft<R>::run(x);
-      if constexpr (!LAST) {
-        constexpr int S1 = K::S(I + 1), RS1 = K::RS(I + 1);
+        for (int k = 1; k < R; ++k) x[it][k] = cmul_w(x[it][k], tw[I][k]);
+      } else {
+        const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(I) + (active ? rest : 0) * R);
 #pragma unroll
-        for (int k = 1; k < R; ++k) x[k] = cmul_w(x[k], tw[I][k]);
+        for (int k2 = 0; k2 < R / 2; ++k2) {
+          const float4 t = t4[k2];
+          if (k2 > 0) x[it][2 * k2] = cmul_w(x[it][2 * k2], (v2f){t.x, t.y});
+          x[it][2 * k2 + 1] = cmul_w(x[it][2 * k2 + 1], (v2f){t.z, t.w});
+        }
+      }
+      if (active) {
         const int n1 = rest / S1, rest2 = rest % S1;
         v2f* d2 = reinterpret_cast<v2f*>(fbuf) + n1 * RS1 + kk * S1 + rest2;
 #pragma unroll
-        for (int k = 0; k < R; ++k) d2[k * KK * S1] = x[k];
-      } else if (f < p.frames) {
-        const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
-        if (p.flags & PFB_FLAG_MAGNITUDE) {
-          float* row = reinterpret_cast<float*>(p.out) + f * M;
-          float* lo = row + kk + shift;
-          float* hi = row + kk + (M / 2 - shift);
-#pragma unroll
-          for (int k = 0; k < R; ++k)
-            *((k < R / 2) ? lo + k * KK : hi + (k - R / 2) * KK) = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
-        } else {
-          float2* row = p.out + f * M;
-          float2* lo = row + kk + shift;
-          float2* hi = row + kk + (M / 2 - shift);
-#pragma unroll
-          for (int k = 0; k < R; ++k) store_c64((k < R / 2) ? lo + k * KK : hi + (k - R / 2) * KK, x[k], p.nontemporal);
-        }
+        for (int k = 0; k < R; ++k) d2[k * KK * S1] = x[it][k];
       }
     }
   }
@@ -722,7 +723,7 @@ struct FastKernel {
   }
 
   PFB_DEV void run_teams(const KernelParams& p, float2* bufs) {
-    static_assert(K::NP == 3 && !K::PINGPONG && !K::TW_TABLE && NT % 64 == 0, "three in-place passes, twiddles in registers");
+    static_assert(K::NP == 3 && !K::PINGPONG && NT % 64 == 0, "three in-place passes");
     const long long f_begin = (long long)blockIdx.x * p.frames_per_block;
     if (f_begin >= p.frames) return;
     const int nch = p.frames_per_block / C;  // even (host rounds); the last workgroup filters zero padding past the end
@@ -742,9 +743,9 @@ struct FastKernel {
       for (int s = 0; s <= nch; ++s) {
         if (s >= 1) {
           float2* fbuf = bufs + b * K::BUF + fr * K::FS;
-          pass_frame<0>(p, fbuf, lane, 0, k.tw);
+          pass_frame<0>(p, fbuf, lane, k.tw);
           team_sync<true>();
-          pass_frame<1>(p, fbuf, lane, 0, k.tw);
+          pass_frame<1>(p, fbuf, lane, k.tw);
           b = (b == 2) ? 0 : b + 1;
         }
         __syncthreads();
@@ -1267,6 +1268,12 @@ hipError_t launch_persistent_pairs(const KernelParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// shapes with a FIR-team / FFT-team instantiation: three in-place passes whose last pass fits the FIR team in one
+// iteration per thread or more (the generic pass), a multi-wave FIR team, chunks of C frames = C FFT waves
+template <class K>
+constexpr bool kTeamsOk = K::NP == 3 && !K::PINGPONG && K::NT > 64 && (K::NT + 64 * K::C) <= 1024 &&
+                          3 * sizeof(float2) * K::BUF <= 160 * 1024 && K::C % 2 == 0;
+
 template <class K>
 __global__ void __launch_bounds__(K::NT + 64 * K::C, K::MIN_WAVES) pfb_teams_kernel(const KernelParams p) {
   __shared__ float2 bufs[3 * K::BUF];
@@ -1331,7 +1338,7 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
     }
   }
   // (measured on cfg3, cfg5 and M=56 too: slower than their sliding runs, so only the M=64 kernels carry it)
-  if constexpr (K::NP == 3 && !K::PINGPONG && !K::TW_TABLE && K::NT > 64 && K::POW2) {  // FIR team + FFT team
+  if constexpr (kTeamsOk<K>) {  // FIR team + FFT team
     if (p.schedule == 6) {
       const long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
       hipLaunchKernelGGL(pfb_teams_kernel<K>, dim3((unsigned)nb), dim3(K::NT + 64 * K::C), 0, s, p);

@@ -217,18 +217,19 @@ def test_fast_and_generic_kernels_agree():
     assert rel(fast, gen) < 2e-6
 
 
-def test_every_registered_plan_variant_matches_the_oracle(oracle):
+@pytest.mark.parametrize("M,P,nvar", [(1024, 16, 3), (560, 12, 2)])
+def test_every_registered_plan_variant_matches_the_oracle(oracle, M, P, nvar):
     """PFB_OPT_VARIANT: the alternative fused plans kept for a shape (cfg4: the FIR-team / FFT-team kernel, 16 waves x
-    1 column 8 x 8 x 16, 8 waves x 2 columns 16 x 16 x 4) all meet the fp32 tolerance, also on a stream that is not
-    a whole number of workgroups; an index past the last registered plan is refused and leaves the handle usable."""
-    M, P = 1024, 16
-    n = M * 1300 + 17
+    1 column 8 x 8 x 16, 8 waves x 2 columns 16 x 16 x 4; M = 560: teams, 9 waves in lockstep) all meet the fp32
+    tolerance, also on a stream that is not a whole number of workgroups; an index past the last registered plan is
+    refused and leaves the handle usable."""
+    n = M * 700 + 17
     iq = synth.pulsed_iq_numpy(n, 12, np.int16, seed=31)
     h = np.random.default_rng(8).standard_normal(M * P).astype(np.float32) / M
     want = oracle_run(oracle, iq, h, M, P, M, 12)
     names = set()
     with Channelizer(M, taps=h, bit_width=12) as ch:
-        for v in range(3):
+        for v in range(nvar):
             ch.set_option(L.PFB_OPT_VARIANT, v)
             ch.reset()
             got = ch(iq)
@@ -239,7 +240,7 @@ def test_every_registered_plan_variant_matches_the_oracle(oracle):
             ch.set_option(L.PFB_OPT_VARIANT, 9)
         ch.reset()
         assert rel(ch(iq), want) < 1e-5
-    assert len(names) == 3
+    assert len(names) == nvar
 
 
 def test_empty_and_tiny_inputs():

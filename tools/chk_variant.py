@@ -2,8 +2,8 @@ import sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from sdr_channelizer_amd import Channelizer, design_prototype, synth
 from sdr_channelizer_amd import _lib as L
-M,P=1024,16
-n=1<<24
+M, P = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 16)
+n = M * 4000 + 5
 dev=torch.device('cuda',0)
 iq=synth.pulsed_iq_torch(n,12,torch.int16,device=dev)
 ch=Channelizer(M,taps=design_prototype(M,P),decimation=M,sample_format='int16',bit_width=12)
