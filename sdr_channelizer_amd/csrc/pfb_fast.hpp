@@ -724,7 +724,12 @@ struct FastKernel {
 
   PFB_DEV void run_teams(const KernelParams& p, float2* bufs) {
     static_assert(K::NP == 3 && !K::PINGPONG && NT % 64 == 0, "three in-place passes");
-    const long long f_begin = (long long)blockIdx.x * p.frames_per_block;
+    long long run = blockIdx.x;
+    if (p.xcd_remap) {  // consecutive runs on one XCD: a run's halo rows are its predecessor's last rows, still in that L2
+      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
+      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
+    }
+    const long long f_begin = run * p.frames_per_block;
     if (f_begin >= p.frames) return;
     const int nch = p.frames_per_block / C;  // even (host rounds); the last workgroup filters zero padding past the end
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
