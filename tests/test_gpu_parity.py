@@ -286,7 +286,7 @@ def test_device_tensor_path_matches_host_path():
         assert np.array_equal(y.cpu().numpy(), host)
 
 
-@pytest.mark.parametrize("M,P,D,fmt,bw,log2n", [(64, 12, 64, "int16", 12, 30), (256, 8, 256, "int8", 8, 30),
+@pytest.mark.parametrize("M,P,D,fmt,bw,log2n", [(64, 12, 64, "int16", 12, 30), (64, 12, 64, "int16", 12, 31), (256, 8, 256, "int8", 8, 30),
                                                 (1024, 16, 1024, "int16", 16, 28), (128, 12, 64, "int16", 12, 28),
                                                 (56, 12, 56, "int16", 12, 26), (560, 12, 560, "int16", 12, 26)])
 def test_large_stream_interior_windows(oracle, M, P, D, fmt, bw, log2n):
