@@ -220,16 +220,23 @@ class Channelizer:
         L.check(self._lib.pfb_get_kernel_times(self._h, buf, 4096, C.byref(n)), "pfb_get_kernel_times")
         return list(buf[: n.value])
 
-    def process_iq_file(self, path: str, reset: bool = True):
+    def process_iq_file(self, path: str, reset: bool = True, out=None):
         """Channelize one .iq record straight from disk (header parsed and checked by the library).
-        Returns (y, info): y is (frames, M) complex64 (or float32 with magnitude=True)."""
+        Returns (y, info): y is (frames, M) complex64 (or float32 with magnitude=True).  ``out``: optional numpy
+        buffer with room for frames * M values (page-locked, see pinned_empty, for the full rate)."""
         from . import iqfile
         with open(path, "rb") as f:
             info = iqfile.parse_header(f.read(128))
         if reset:
             self.reset()  # a fresh channelizer per file, create_pdws_channelized.m:33
         F = self.frames_for(int(info.packet.numSamples))
-        res = np.empty((F, self.num_bands), dtype=np.float32 if self.magnitude else np.complex64)
+        dt = np.float32 if self.magnitude else np.complex64
+        if out is None:
+            res = np.empty((F, self.num_bands), dtype=dt)
+        else:
+            if out.dtype != dt or out.size < F * self.num_bands or not out.flags.c_contiguous:
+                raise ValueError("out must be a C-contiguous array of the output dtype with room for frames*M values")
+            res = out.reshape(-1)[: F * self.num_bands].reshape(F, self.num_bands)
         f_out = C.c_uint64()
         got = L.PfbIqInfo()
         L.check(self._lib.pfb_process_iq_file(self._h, path.encode(), C.c_void_p(res.ctypes.data), F, C.byref(f_out),

@@ -13,6 +13,7 @@
 #include <new>
 #include <string>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "pfb_common.h"
@@ -520,19 +521,38 @@ int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap
   if (frames_out) *frames_out = need;
   if (need > cap) { std::fclose(f); return PFB_ERR_CAPACITY; }
   if (need > 0 && !out) { std::fclose(f); return PFB_ERR_BAD_ARG; }
+  // Two page-locked chunk buffers: a reader thread fills one from the file while the other crosses PCIe and is
+  // transformed (the staged host path overlaps its own copy-in / transform / copy-out underneath).
   const uint64_t chunk = (((uint64_t)1 << 24) / h->D) * h->D;  // whole frames, 64 MB of int16 I/Q
-  std::vector<char> buf((size_t)std::min<uint64_t>(chunk, n ? n : 1) * h->bps);
+  const size_t chunk_bytes = (size_t)std::min<uint64_t>(chunk, n ? n : 1) * h->bps;
+  char* bufs[2] = {static_cast<char*>(pfb_host_alloc(chunk_bytes)), static_cast<char*>(pfb_host_alloc(chunk_bytes))};
+  if (!bufs[0] || !bufs[1]) {
+    pfb_host_free(bufs[0]);
+    pfb_host_free(bufs[1]);
+    std::fclose(f);
+    return PFB_ERR_NO_MEMORY;
+  }
   std::fseek(f, (long)info.header_bytes, SEEK_SET);
+  auto read_chunk = [&](char* dst, uint64_t m) { return std::fread(dst, (size_t)h->bps, (size_t)m, f) == (size_t)m; };
   uint64_t done = 0, frames_done = 0;
-  while (done < n && rc == PFB_OK) {
+  bool have = n > 0 && read_chunk(bufs[0], std::min<uint64_t>(chunk, n));
+  if (n > 0 && !have) rc = PFB_ERR_BAD_FORMAT;
+  for (uint64_t i = 0; done < n && rc == PFB_OK; ++i) {
     const uint64_t m = std::min<uint64_t>(chunk, n - done);
-    if (std::fread(buf.data(), (size_t)h->bps, (size_t)m, f) != (size_t)m) { rc = PFB_ERR_BAD_FORMAT; break; }
+    const uint64_t m_next = std::min<uint64_t>(chunk, n - done - m);
+    bool next_ok = true;
+    std::thread reader;
+    if (m_next > 0) reader = std::thread([&, i, m_next] { next_ok = read_chunk(bufs[(i + 1) & 1], m_next); });
     uint64_t fr = 0;
-    rc = pfb_process(h, buf.data(), m, static_cast<char*>(out) + frames_done * h->M * h->out_elem, cap - frames_done, &fr,
+    rc = pfb_process(h, bufs[i & 1], m, static_cast<char*>(out) + frames_done * h->M * h->out_elem, cap - frames_done, &fr,
                      PFB_MEM_HOST);
+    if (reader.joinable()) reader.join();
+    if (rc == PFB_OK && !next_ok) rc = PFB_ERR_BAD_FORMAT;
     done += m;
     frames_done += fr;
   }
+  pfb_host_free(bufs[0]);
+  pfb_host_free(bufs[1]);
   std::fclose(f);
   if (frames_out) *frames_out = frames_done;
   return rc;
