@@ -176,7 +176,8 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
       int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
       fpb = ((fpb + c - 1) / c) * c;
       p.schedule = h->opt_schedule >= 0 ? h->opt_schedule : h->fast->default_schedule;
-      if (h->layout == PFB_LAYOUT_CHANNEL_MAJOR) p.schedule = 0;  // the channel-major instantiation is the sliding-run kernel
+      if (h->layout == PFB_LAYOUT_CHANNEL_MAJOR)  // channel-major: 0 = sliding runs, 2 = tiles, anything else = the kernel's pick
+        p.schedule = (h->opt_schedule == 0 || h->opt_schedule == 2) ? h->opt_schedule : -1;
       if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
       if (p.schedule == 6) fpb = ((fpb + 2 * c - 1) / (2 * c)) * (2 * c);  // the team kernel walks chunks in pairs
       if (p.schedule == 4 || p.schedule == 5) {

@@ -1188,10 +1188,11 @@ hipError_t init_tables(const float* taps, const float2* tw, float* taps_lane, fl
   return hipGetLastError();
 }
 
-// plans whose channel-major instantiation does not fit their register budget (the 1024-thread cfg4 plan sits
-// at its 128-VGPR ceiling already): channel-major handles get the shape's next registered plan instead
+// plans without a channel-major instantiation: it does not fit the register budget (the 1024-thread cfg4 plan
+// sits at its 128-VGPR ceiling already) or would be the shape's worst (chunks of 4 frames); channel-major
+// handles get the shape's next registered plan instead
 template <class K>
-constexpr bool kChannelMajorOk = K::NT < 1024;
+constexpr bool kChannelMajorOk = K::NT < 1024 && !(K::NP == 3 && K::C == 4);  // (C = 4 team plans: 32-byte runs)
 
 template <class K, bool CM = false>
 __global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_fast_kernel(const KernelParams p) {
@@ -1205,17 +1206,17 @@ __global__ void __launch_bounds__(K::NT, (K::MIN_WAVES > 3 ? 3 : K::MIN_WAVES)) 
   FastKernel<K>::run_strided(p, lds);
 }
 
-template <class K, int NWV>
+template <class K, int NWV, bool CM = false>
 __global__ void __launch_bounds__(64 * NWV) pfb_tile_kernel(const KernelParams p) {
   __shared__ float2 lds[NWV * K::LDS_ELEMS];
-  FastKernel<K>::template run_tile<NWV>(p, lds);
+  FastKernel<K, CM>::template run_tile<NWV>(p, lds);
 }
 
-template <class K, int NWV>
+template <class K, int NWV, bool CM = false>
 hipError_t launch_tile(const KernelParams& p, hipStream_t s) {
   const long long nchunks = (p.frames + K::C - 1) / K::C;
   const long long tiles = (nchunks + NWV - 1) / NWV;
-  hipLaunchKernelGGL((pfb_tile_kernel<K, NWV>), dim3((unsigned)tiles), dim3(64 * NWV), 0, s, p);
+  hipLaunchKernelGGL((pfb_tile_kernel<K, NWV, CM>), dim3((unsigned)tiles), dim3(64 * NWV), 0, s, p);
   return hipGetLastError();
 }
 
@@ -1335,6 +1336,16 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   if (p.frames <= 0) return hipSuccess;
   if (p.layout == PFB_LAYOUT_CHANNEL_MAJOR) {  // sliding runs only; the other schedules are frame-major tuning
     if constexpr (kChannelMajorOk<K>) {
+      if constexpr (K::NT == 64) {
+        // one chunk per wave, NWV adjacent chunks per workgroup: the workgroup writes NWV * C consecutive frames of
+        // every channel at about the same time, which L2 merges into runs a sliding wave never produces by itself
+        // (measured +17 ... +70 % over sliding runs; 16 waves win up to M = 64, 8 above).  schedule -1 = this default.
+        if (p.schedule == 2 || p.schedule < 0) {
+          const int nwv = p.schedule < 0 ? (K::M <= 64 ? 16 : 8) : p.tile_waves;
+          if (nwv == 16) return launch_tile<K, 16, true>(p, s);
+          return launch_tile<K, 8, true>(p, s);
+        }
+      }
       const long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
       hipLaunchKernelGGL((pfb_fast_kernel<K, true>), dim3((unsigned)nb), dim3(K::NT), 0, s, p);
       return hipGetLastError();

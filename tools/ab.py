@@ -24,6 +24,7 @@ DEFAULTS = {"kernel": 2, "fpb": 0, "nt": 0, "remap": -1, "sched": -1, "grid": 0,
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2-samples", type=int, default=30)
+ap.add_argument("--samples", type=int, default=0, help="exact sample count (overrides --log2-samples)")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--workload", default="64,12,64,int16,12")
@@ -36,7 +37,7 @@ a = ap.parse_args()
 
 M, P, D, fmt, bw = a.workload.split(",")
 M, P, D, bw = int(M), int(P), int(D), int(bw)
-n = 1 << a.log2_samples
+n = a.samples if a.samples > 0 else 1 << a.log2_samples
 dev = torch.device("cuda", 0)
 iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device=dev)
 odt = torch.float32 if a.magnitude else torch.complex64
