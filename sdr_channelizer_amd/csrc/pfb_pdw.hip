@@ -798,8 +798,27 @@ __global__ void __launch_bounds__(256) pdw_pulse_kernel(Src src, int M, const lo
     return d;
   };
   double med;
-  if (n - 1 <= CACHE) {
-    for (long long i = threadIdx.x; i < n - 1; i += blockDim.x) cache[i] = dphi(i);
+  if (n <= CACHE) {  // one atan2 per sample: phases into the cache, steps into registers, steps back into the cache
+    constexpr int PER = (CACHE + 255) / 256;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) cache[i] = src.phase(toa + i, pcol);
+    __syncthreads();
+    double step[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const long long i = threadIdx.x + (long long)j * 256;
+      if (i < n - 1) {
+        double d = cache[i + 1] - cache[i];
+        if (d < -180.0) d += 360.0;
+        if (d > 180.0) d -= 360.0;
+        step[j] = d;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const long long i = threadIdx.x + (long long)j * 256;
+      if (i < n - 1) cache[i] = step[j];
+    }
     __syncthreads();
     med = (n - 1 <= kCountingMedian) ? cached_median(cache, (int)(n - 1), mid)
                                      : block_median([&](long long i) { return cache[i]; }, n - 1, hist, pick);
