@@ -286,6 +286,24 @@ def test_device_tensor_path_matches_host_path():
         assert np.array_equal(y.cpu().numpy(), host)
 
 
+@pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (256, 8, 256, "int8", 8), (1024, 16, 1024, "int16", 16),
+                                          (128, 12, 64, "int16", 12)])
+def test_bench_stream_prefix_of_2e20_samples(oracle, M, P, D, fmt, bw):
+    """SURVEY.md section 8d's error metric: max|y_gpu - y_oracle| / max|y_oracle| <= 1e-5 on a 2^20-sample prefix of
+    the benchmark's own synthetic stream (same generator, same seed, same prototype as bench.py)."""
+    import torch
+    from sdr_channelizer_amd import design_prototype
+    n = 1 << 20
+    iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, seed=synth.SEED, device="cuda")
+    h = design_prototype(M, P, 80.0)
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw) as ch:
+        ch.set_option(L.PFB_OPT_KERNEL, 2)
+        y = ch(iq).cpu().numpy()
+    want = oracle_run(oracle, iq.cpu().numpy(), h, M, P, D, bw)
+    assert y.shape == want.shape == (n // D, M)
+    assert rel(y, want) < REL_TOL
+
+
 @pytest.mark.parametrize("M,P,D,fmt,bw,log2n", [(64, 12, 64, "int16", 12, 30), (64, 12, 64, "int16", 12, 31), (256, 8, 256, "int8", 8, 30),
                                                 (1024, 16, 1024, "int16", 16, 28), (128, 12, 64, "int16", 12, 28),
                                                 (56, 12, 56, "int16", 12, 26), (560, 12, 560, "int16", 12, 26)])
