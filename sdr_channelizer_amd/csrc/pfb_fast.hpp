@@ -1342,7 +1342,9 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
         // (measured +17 ... +70 % over sliding runs; 16 waves win up to M = 64, 8 above).  schedule -1 = this default.
         if (p.schedule == 2 || p.schedule < 0) {
           const int nwv = p.schedule < 0 ? (K::M <= 64 ? 16 : 8) : p.tile_waves;
-          if (nwv == 16) return launch_tile<K, 16, true>(p, s);
+          if constexpr (16 * sizeof(float2) * K::LDS_ELEMS <= 160 * 1024) {
+            if (nwv == 16) return launch_tile<K, 16, true>(p, s);
+          }
           return launch_tile<K, 8, true>(p, s);
         }
       }
