@@ -193,9 +193,10 @@ typedef enum pfb_option {
                                 /* sliding runs whose halo rows are shared through LDS, 4 = 3    */
                                 /* with the FIR and the FFT on different waves (M = 64 kernels), */
                                 /* 5 = 4 with resident workgroups walking strided tiles (int16), */
-                                /* 6 = FIR team + FFT team in one workgroup (the M = 1024 plan)  */
+                                /* 6 = FIR team + FFT team in one workgroup (the M = 1024 plan), */
+                                /* 7 = a FIR wave + an FFT wave per long sliding run             */
   PFB_OPT_GRID = 7,             /* schedules 1/5: workgroups to launch (0 = all that are resident) */
-  PFB_OPT_TILE_WAVES = 8,       /* schedules 2/3: waves, 4/5: wave pairs per workgroup           */
+  PFB_OPT_TILE_WAVES = 8,       /* schedules 2/3: waves, 4/5/7: wave pairs per workgroup         */
   PFB_OPT_EXPERIMENT = 9,       /* bit mask of timing experiments; 0 in production               */
   PFB_OPT_VARIANT = 10          /* n-th fused kernel registered for this shape (0 = default plan) */
 } pfb_option;

@@ -949,6 +949,87 @@ struct FastKernel {
     }
   }
 
+  // ---- schedule H: wave pairs over long sliding runs ------------------------------------------------------
+  // Schedule F's split of the work (a FIR wave and an FFT wave per run, an LDS double buffer between them, one
+  // workgroup barrier per chunk) without its halo sharing: every pair slides over its own long run of
+  // frames_per_block frames like schedule A and re-reads only its own W-1 halo rows once.  For the shapes whose
+  // single-wave kernel needs close to 200 registers (cfg5: 24 taps and a 31-row window per lane plus a radix-16
+  // pass) this halves the registers per wave and doubles the waves per CU; the runs are a runtime loop, so
+  // they can be long.
+  template <bool INTERIOR>
+  PFB_DEV void pair_fir_run(const KernelParams& p, const Consts& k, float2* bufs, long long f_begin, int nch) {
+    const int tid = threadIdx.x & 63;
+    const int c0 = tid * CPT;
+    const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
+    v2f x[NW][CPT];
+    raw_t raw[C][CPT];
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) {
+      raw_t t[CPT];
+      load_row<INTERIOR>(p, run_ptr, f_begin - (W - 1) + i, i, c0, t);
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(t[cc]);
+    }
+#pragma unroll
+    for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + t, W - 1 + t, c0, raw[t]);
+    for (int ci2 = 0; ci2 < nch; ci2 += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ci = ci2 + u;
+#pragma unroll
+        for (int t = 0; t < C; ++t)
+#pragma unroll
+          for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);
+        if (ci + 1 < nch) {
+          const long long rel = (long long)(ci + 1) * C + (W - 1);
+#pragma unroll
+          for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + (long long)(ci + 1) * C + t, rel + t, c0, raw[t]);
+        }
+        fir_to_lds(k, x, bufs + u * K::BUF, tid);
+#pragma unroll
+        for (int i = 0; i < W - 1; ++i)
+#pragma unroll
+          for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
+        __syncthreads();  // chunk ci handed to the FFT wave
+      }
+    }
+    __syncthreads();      // the FFT wave's last step
+  }
+
+  template <int NPAIR>
+  PFB_DEV void run_pairs_sliding(const KernelParams& p, float2* lds_fft) {
+    static_assert(NT == 64 && K::NP == 2 && !K::PINGPONG, "one wave per role, two in-place passes");
+    const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    const bool fir_role = wave < NPAIR;
+    const int pair = fir_role ? wave : wave - NPAIR;
+    long long blk = blockIdx.x;
+    if (p.xcd_remap) {
+      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = blk & 7;
+      blk = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (blk >> 3);
+    }
+    const long long f_begin = (blk * NPAIR + pair) * (long long)p.frames_per_block;
+    const int nch = p.frames_per_block / C;  // even (host rounds); pairs past the end of the stream idle through the barriers
+    float2* bufs = lds_fft + pair * 2 * K::BUF;
+    Consts k;
+    setup(p, tid, k);
+    if (fir_role) {
+      const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_begin + p.frames_per_block <= p.frames);
+      if (f_begin >= p.frames) {
+        for (int s = 0; s <= nch; ++s) __syncthreads();
+      } else if (interior) {
+        pair_fir_run<true>(p, k, bufs, f_begin, nch);
+      } else {
+        pair_fir_run<false>(p, k, bufs, f_begin, nch);
+      }
+    } else {
+#pragma unroll 1
+      for (int s = 0; s <= nch; ++s) {
+        if (s >= 1 && f_begin < p.frames) fft_from_lds(p, k, bufs + ((s - 1) & 1) * K::BUF, tid, f_begin + (long long)(s - 1) * C);
+        __syncthreads();
+      }
+    }
+  }
+
   // ---- schedule G: persistent wave pairs ------------------------------------------------------------
   // Schedule F's workgroups are short-lived (NPAIR * L frames, a dozen microseconds) and only one fits a CU
   // (LDS), so every workgroup's start-up -- table loads, W-1 halo rows and the first chunk from HBM, the
@@ -1274,6 +1355,20 @@ hipError_t launch_persistent_pairs(const KernelParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <class K, int NPAIR, int MINW>
+__global__ void __launch_bounds__(128 * NPAIR, MINW) pfb_pairs_sliding_kernel(const KernelParams p) {
+  __shared__ float2 lds_fft[NPAIR * 2 * K::BUF];
+  FastKernel<K>::template run_pairs_sliding<NPAIR>(p, lds_fft);
+}
+
+template <class K, int NPAIR, int MINW>
+hipError_t launch_pairs_sliding(const KernelParams& p, hipStream_t s) {
+  const long long per = (long long)NPAIR * p.frames_per_block;
+  const long long blocks = (p.frames + per - 1) / per;
+  hipLaunchKernelGGL((pfb_pairs_sliding_kernel<K, NPAIR, MINW>), dim3((unsigned)blocks), dim3(128 * NPAIR), 0, s, p);
+  return hipGetLastError();
+}
+
 // shapes with a FIR-team / FFT-team instantiation: three in-place passes whose last pass fits the FIR team in one
 // iteration per thread or more (the generic pass), a multi-wave FIR team, chunks of C frames = C FFT waves
 template <class K>
@@ -1356,6 +1451,18 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
     }
   }
   // (measured on cfg3, cfg5 and M=56 too: slower than their sliding runs, so only the M=64 kernels carry it)
+  if constexpr (K::NT == 64 && K::NP == 2 && !K::PINGPONG) {  // wave pairs over long sliding runs
+    if (p.schedule == 7) {
+      // 8 pairs (16 waves, 128 registers each) where the roles fit that budget -- the shapes whose single-wave
+      // kernel already runs 4 waves per SIMD -- otherwise 6 pairs (168 registers); tile_waves = 4 asks for 4
+      constexpr size_t kPair = sizeof(float2) * 2 * K::BUF;
+      if (p.tile_waves == 4) return launch_pairs_sliding<K, 4, 2>(p, s);
+      if constexpr (K::MIN_WAVES >= 4 && 8 * kPair <= 160 * 1024) {
+        if (p.tile_waves >= 8) return launch_pairs_sliding<K, 8, 4>(p, s);
+      }
+      return launch_pairs_sliding<K, 6, 3>(p, s);
+    }
+  }
   if constexpr (kTeamsOk<K>) {  // FIR team + FFT team
     if (p.schedule == 6) {
       const long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;

@@ -194,7 +194,8 @@ using Cfg64x12i16 = FastCfg<64, 12, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 8, 1, 8, 9
 using Cfg64x12i8  = FastCfg<64, 12, 64, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
 using Cfg64x12f32 = FastCfg<64, 12, 64, 1, PFB_FMT_CF32,     8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
 // cfg5: 2x oversampled, 24 taps per column, 128 = 16 x 8 (final-pass LDS reads are 2-way conflicted:
-// no single frame stride serves both passes, tools/fft_plan_model.py)
+// no single frame stride serves both passes, tools/fft_plan_model.py); schedule 7 (6 FIR/FFT wave pairs per
+// workgroup) measured within noise of one wave doing both (+0..3 %), so the default stays schedule 0
 using Cfg128x12os2i16 = FastCfg<128, 12, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 16, 8, 1, 8, 17, 0, 136, false, 2>;
 // cfg3: 4 adjacent columns per lane (8-byte loads of int8 I/Q), 256 = 16 x 16, conflict-free
 using Cfg256x8i8  = FastCfg<256, 8, 256, 4, PFB_FMT_INT8_IQ,  4, 2, 16, 16, 1, 16, 17, 0, 272, false, 2>;
@@ -213,7 +214,8 @@ using Cfg1024x16i16b =
 
 
 // the reference's own band count: numBands = fs*1e-6 = 56 (channelizer_example.m:29, generate_pulsed_iq.m:12),
-// 56 = 8 x 7; 56 of the wave's 64 lanes own columns (2-way LDS conflicts on about half the accesses)
+// 56 = 8 x 7; 56 of the wave's 64 lanes own columns (2-way LDS conflicts on about half the accesses); default
+// schedule 7 (8 FIR/FFT wave pairs per workgroup over sliding runs of 512 frames, +17 %)
 using Cfg56x12i16 = FastCfg<56, 12, 56, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
 using Cfg56x12i8  = FastCfg<56, 12, 56, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
 
@@ -256,8 +258,8 @@ static const FastEntry kFastTable[] = {
     entry<Cfg1024x16i16t>("pfb_fast<M1024,P16,D1024,int16>", 512, 6),
     entry<Cfg1024x16i16b>("pfb_fast<M1024,P16,D1024,int16,16w>", 256, 0),
     entry<Cfg1024x16i16>("pfb_fast<M1024,P16,D1024,int16,8w>", 256, 0),
-    entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 0),
-    entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 0),
+    entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 7),
+    entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 7),
     entry<Cfg560x12i16t>("pfb_fast<M560,P12,D560,int16>", 128, 6),
     entry<Cfg560x12i8t>("pfb_fast<M560,P12,D560,int8>", 128, 6),
     entry<Cfg560x12i16>("pfb_fast<M560,P12,D560,int16,9w>", 252, 0),

@@ -490,6 +490,27 @@ def test_page_locked_host_buffers_and_pipelined_staging():
             assert np.array_equal(ch(iq), ref)   # pageable memory, same pipeline
 
 
+@pytest.mark.parametrize("M,P,D,fmt,bw,pairs", [(128, 12, 64, "int16", 12, 6), (128, 12, 64, "int16", 12, 4), (56, 12, 56, "int16", 12, 8),
+                                                (256, 8, 256, "int8", 8, 4), (64, 12, 64, "int16", 12, 8)])
+def test_pairs_over_sliding_runs_give_identical_bits(M, P, D, fmt, bw, pairs):
+    """schedule 7: a FIR wave and an FFT wave per long sliding run; streams that end mid-run and mid-workgroup (whole
+    pairs idle), calls cut mid-run"""
+    n = D * 5003 + 11
+    iq = synth.pulsed_iq_numpy(n, bw, np.int8 if fmt == "int8" else np.int16, seed=17)
+    h = np.random.default_rng(12).standard_normal(M * P).astype(np.float32) / M
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, derotate=(D != M)) as ch:
+        ch.set_option(L.PFB_OPT_SCHEDULE, 0)
+        ref = ch(iq)
+        for fpb in (64, 256):
+            ch.reset()
+            ch.set_option(L.PFB_OPT_SCHEDULE, 7)
+            ch.set_option(L.PFB_OPT_TILE_WAVES, pairs)
+            ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, fpb)
+            cut = D * 1777 + 5
+            got = np.concatenate([ch(iq[:cut]), ch(iq[cut:])])
+            assert np.array_equal(got, ref), fpb
+
+
 def test_iq_file_front_end(oracle, tmp_path):
     """pfb_process_iq_file: record from disk -> channels, and its checks (format mismatch, truncated payload)."""
     import os
