@@ -58,7 +58,7 @@ def test_cfg2_uses_the_fast_kernel(golden_dir):
 @pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (64, 12, 64, "int8", 8), (256, 8, 256, "int8", 8),
                                           (128, 12, 64, "int16", 12), (1024, 16, 1024, "int16", 16),
                                           (56, 12, 56, "int16", 12), (8, 12, 8, "int16", 12),
-                                          (560, 12, 560, "int16", 12), (560, 12, 560, "int8", 8)])
+                                          (560, 12, 560, "int16", 12), (560, 12, 560, "int8", 8), (56, 12, 56, "int8", 8)])
 @pytest.mark.parametrize("q0", [0, 3])
 def test_one_hot_tap_bit_exact(M, P, D, fmt, bw, q0):
     """h = delta[n - M q0] => every channel of frame m equals x[mD + D-1 - M q0] exactly:
@@ -82,7 +82,8 @@ def test_one_hot_tap_bit_exact(M, P, D, fmt, bw, q0):
     (64, 12, 64, "int16", 12, 1 << 18), (64, 12, 64, "int8", 8, 1 << 16), (64, 12, 64, "cf32", 0, 1 << 16),
     (256, 8, 256, "int8", 8, 1 << 17), (128, 12, 64, "int16", 12, 1 << 16), (1024, 16, 1024, "int16", 16, 1 << 18),
     (32, 12, 32, "int16", 12, 1 << 14), (16, 4, 8, "int16", 16, 1 << 12), (56, 12, 56, "int16", 12, 56 * 300),
-    (12, 5, 4, "int8", 8, 4 * 500), (560, 12, 560, "int16", 12, 560 * 150 + 31), (560, 12, 560, "int8", 8, 560 * 64)])
+    (12, 5, 4, "int8", 8, 4 * 500), (560, 12, 560, "int16", 12, 560 * 150 + 31), (560, 12, 560, "int8", 8, 560 * 64),
+    (56, 12, 56, "int8", 8, 56 * 1500 + 3)])
 def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     rng = np.random.default_rng(n + M)
     if fmt == "cf32":
