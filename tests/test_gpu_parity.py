@@ -535,3 +535,35 @@ def test_iq_file_front_end(oracle, tmp_path):
         with pytest.raises(PfbError) as e:
             ch.process_iq_file(path)
         assert e.value.status == L.PFB_ERR_BAD_FORMAT
+
+
+def test_cpp_host_loop_without_python(oracle, tmp_path):
+    """examples/iq_channelize.cpp -- the recorder-shaped C++ loop over the C ABI -- built with g++ and run as its own
+    process (no torch, no Python in it): two records of different formats, output files equal to the Python path's."""
+    import shutil
+    import subprocess
+    from sdr_channelizer_amd import LIB_PATH, iqfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = shutil.which("g++") or shutil.which("hipcc")
+    if cxx is None:
+        pytest.skip("no C++ compiler on this box")
+    exe = os.path.join(tmp_path, "iq_channelize")
+    libdir = os.path.dirname(LIB_PATH)
+    subprocess.run([cxx, "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "iq_channelize.cpp"),
+                    "-o", exe, "-L" + libdir, "-lpfb_channelizer", "-Wl,-rpath," + libdir], check=True)
+    M, P = 64, 12
+    recs = []
+    for name, dt, bw, marker in (("a.iq", np.int16, 12, 0x03030303), ("b.iq", np.int8, 8, 0x02020202)):
+        iq = synth.pulsed_iq_numpy(M * 2500 + 5, bw, dt, seed=bw)
+        path = os.path.join(tmp_path, name)
+        iqfile.write_iq(path, iq, fs=56e6, fc=915e6, bit_width=bw, marker=marker)
+        recs.append((path, iq, "int8" if dt == np.int8 else "int16", bw))
+    out = subprocess.run([exe, str(M), str(P)] + [r[0] for r in recs], check=True, capture_output=True, text=True).stdout
+    assert out.count("frames x 64 channels") == 2 and "pfb_fast<M64" in out
+    h = oracle.design_prototype(M, P).astype(np.float32)   # the same Kaiser design pfb_design_prototype makes
+    for path, iq, fmt, bw in recs:
+        got = np.fromfile(path + ".chan", dtype=np.complex64).reshape(-1, M)
+        with Channelizer(M, taps=h, sample_format=fmt, bit_width=bw, fftshift=True) as ch:
+            want = ch(iq)
+        assert got.shape == want.shape
+        assert rel(got, want) < 2e-6   # taps designed in C (float) vs by the oracle (double, then rounded)
