@@ -27,6 +27,17 @@
 //
 // No MFMA: 4P + 5 log2 M flop per sample against 12 B of HBM traffic -- the
 // kernel is HBM-bound.
+//
+// The arithmetic above is shared by several SCHEDULES (who computes which frames
+// when; PFB_OPT_SCHEDULE, bit-identical outputs per shape):
+//   0 (A)  one sliding run per workgroup, FIR and FFT by the same threads
+//   1 (B)  persistent workgroups over strided chunks          (access-shape study)
+//   2 (C)  one chunk per wave, adjacent chunks per workgroup  (channel-major default)
+//   3 (D)  short runs whose halo rows are shared through LDS
+//   4 (F)  D with a FIR wave and an FFT wave per run          (M = 64 default)
+//   5 (G)  F with resident workgroups, halo prefetched HBM -> LDS
+//   6 (T)  a FIR team and an FFT team per workgroup           (M = 1024 / 560 default)
+//   7 (H)  a FIR wave and an FFT wave per long sliding run    (M = 56 default)
 #pragma once
 
 #include "pfb_common.h"
