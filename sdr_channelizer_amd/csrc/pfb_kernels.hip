@@ -250,7 +250,7 @@ constexpr FastEntry entry(const char* name, int default_fpb, int default_schedul
 
 static const FastEntry kFastTable[] = {
     entry<Cfg64x12i16>("pfb_fast<M64,P12,D64,int16>", 512, 4),
-    entry<Cfg64x12i8>("pfb_fast<M64,P12,D64,int8>", 512, 4),
+    entry<Cfg64x12i8>("pfb_fast<M64,P12,D64,int8>", 256, 7),  // 8-bit rows are half as long: pairs over long runs beat the shared-halo tiles by 10 %
     entry<Cfg64x12f32>("pfb_fast<M64,P12,D64,cf32>", 512, 4),
     entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 512, 0),
     entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 256, 0),
