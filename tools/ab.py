@@ -39,7 +39,10 @@ M, P, D, fmt, bw = a.workload.split(",")
 M, P, D, bw = int(M), int(P), int(D), int(bw)
 n = a.samples if a.samples > 0 else 1 << a.log2_samples
 dev = torch.device("cuda", 0)
-iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device=dev)
+if fmt == "cf32":
+    iq = torch.randn((n, 2), dtype=torch.float32, device=dev)
+else:
+    iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device=dev)
 odt = torch.float32 if a.magnitude else torch.complex64
 if a.channel_major:
     out = torch.empty((M, n // D + 1), dtype=odt, device=dev)  # +1: a carried tail can complete one more frame
@@ -50,7 +53,7 @@ else:
     big = torch.empty((n // D + 1 + pad_rows, M), dtype=odt, device=dev)
     out = big[pad_rows - 1:]
 print(f"# in ptr {iq.data_ptr():#x} out ptr {out.data_ptr():#x} delta {(out.data_ptr() - iq.data_ptr()) / 2**20:.3f} MiB")
-ch = Channelizer(M, taps=design_prototype(M, P), decimation=D, sample_format=fmt, bit_width=bw, magnitude=a.magnitude,
+ch = Channelizer(M, taps=design_prototype(M, P), decimation=D, sample_format=fmt, bit_width=max(bw, 1), magnitude=a.magnitude,
                  channel_major=a.channel_major)
 ch.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 cases = []
@@ -62,7 +65,7 @@ for c in a.cases:
         opts[k] = int(v)
     cases.append((name, opts))
 times = {name: [] for name, _ in cases}
-bytes_per_sample = (2 if fmt == "int8" else 4) + (4 if a.magnitude else 8) * (M // D)
+bytes_per_sample = {"int8": 2, "int16": 4, "cf32": 8}[fmt] + (4 if a.magnitude else 8) * (M // D)
 ch.set_option(L.PFB_OPT_PROFILE, 1)
 for r in range(a.rounds + 1):
     for name, opts in cases:
