@@ -205,6 +205,30 @@ template <> struct Dft<10> {
   }
 };
 
+// 14 = 2 x 7 (560 = 14 x 10 x 4 keeps every non-final pass of the team kernel at one item per lane)
+template <> struct Dft<14> {
+  PFB_DEV void run(v2f (&x)[14]) {
+    // W_14^k = e^{+j 2 pi k / 14}, k = 1..6
+    constexpr float c1 = 0.90096886790241915f, s1 = 0.43388373911755812f;
+    constexpr float c2 = 0.62348980185873359f, s2 = 0.78183148246802980f;
+    constexpr float c3 = 0.22252093395631445f, s3 = 0.97492791218182362f;
+    v2f e[7], o[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { e[k] = x[2 * k]; o[k] = x[2 * k + 1]; }
+    Dft<7>::run(e);
+    Dft<7>::run(o);
+    const v2f t1 = cmul(o[1], c1, s1), t2 = cmul(o[2], c2, s2), t3 = cmul(o[3], c3, s3);
+    const v2f t4 = cmul(o[4], -c3, s3), t5 = cmul(o[5], -c2, s2), t6 = cmul(o[6], -c1, s1);
+    x[0] = e[0] + o[0]; x[7] = e[0] - o[0];
+    x[1] = e[1] + t1;   x[8] = e[1] - t1;
+    x[2] = e[2] + t2;   x[9] = e[2] - t2;
+    x[3] = e[3] + t3;   x[10] = e[3] - t3;
+    x[4] = e[4] + t4;   x[11] = e[4] - t4;
+    x[5] = e[5] + t5;   x[12] = e[5] - t5;
+    x[6] = e[6] + t6;   x[13] = e[6] - t6;
+  }
+};
+
 template <int N, int K>
 struct DftCombine {
   PFB_DEV void run(v2f (&x)[N], const v2f (&e)[N / 2], const v2f (&o)[N / 2]) {

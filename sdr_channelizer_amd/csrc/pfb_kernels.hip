@@ -232,12 +232,13 @@ using Cfg560x12i8 =
 // workgroup barrier per chunk (pfb_fast.hpp, schedule T)
 using Cfg1024x16i16t =
     FastCfg<1024, 16, 1024, 2, PFB_FMT_INT16_IQ, 4, 3, 16, 16, 4, 64, 68, 260, 1088, false, 3, false>;
-// M = 560, team plan (the default, +3..5 % over the 9-wave lockstep plan above): 280 FIR threads x 2 columns
-// (5 waves) + 4 FFT waves, chunks of 4 frames; pass 1 has 70 items per frame = two iterations per FFT wave
+// M = 560, team plan (the default): 280 FIR threads x 2 columns (5 waves) + 4 FFT waves, chunks of 4 frames,
+// 560 = 14 x 10 x 4 so that both FFT-team passes are one item per lane (40 and 56 of 64 lanes; with 10 x 8 x 7 the
+// second pass needed two iterations and the FFT team was the bottleneck: 1.00 -> 0.83-0.87 ms)
 using Cfg560x12i16t =
-    FastCfg<560, 12, 560, 2, PFB_FMT_INT16_IQ, 4, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, false>;
+    FastCfg<560, 12, 560, 2, PFB_FMT_INT16_IQ, 4, 3, 14, 10, 4, 40, 60, 140, 600, false, 3, false>;
 using Cfg560x12i8t =
-    FastCfg<560, 12, 560, 2, PFB_FMT_INT8_IQ, 4, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, false>;
+    FastCfg<560, 12, 560, 2, PFB_FMT_INT8_IQ, 4, 3, 14, 10, 4, 40, 60, 140, 600, false, 3, false>;
 
 struct FastEntry { int M, P, D, fmt; FastKernelInfo info; };
 
@@ -260,8 +261,8 @@ static const FastEntry kFastTable[] = {
     entry<Cfg1024x16i16>("pfb_fast<M1024,P16,D1024,int16,8w>", 256, 0),
     entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 7),
     entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 7),
-    entry<Cfg560x12i16t>("pfb_fast<M560,P12,D560,int16>", 128, 6),
-    entry<Cfg560x12i8t>("pfb_fast<M560,P12,D560,int8>", 128, 6),
+    entry<Cfg560x12i16t>("pfb_fast<M560,P12,D560,int16>", 512, 6),
+    entry<Cfg560x12i8t>("pfb_fast<M560,P12,D560,int8>", 512, 6),
     entry<Cfg560x12i16>("pfb_fast<M560,P12,D560,int16,9w>", 252, 0),
     entry<Cfg560x12i8>("pfb_fast<M560,P12,D560,int8,9w>", 252, 0),
 };
