@@ -194,11 +194,20 @@ __global__ void __launch_bounds__(256) pdw_hist_kernel(const float2* y, long lon
   const long long r0 = (long long)blockIdx.y * rows_per_block;
   const long long r1 = (r0 + rows_per_block < F) ? r0 + rows_per_block : F;
   if (valid) {
-    for (long long r = r0 + wave; r < r1; r += 4) {
-      const unsigned long long k = dkey(mag2_of(y[sample_row(r, stride) * M + col]));  // ordered like the magnitude, no sqrt
+    auto count = [&](float2 v) {
+      const unsigned long long k = dkey(mag2_of(v));  // ordered like the magnitude, no sqrt
       const bool in_bucket = (pass == 0) || ((k >> (shift + 8)) == (pre >> (shift + 8)));
       if (in_bucket) atomicAdd(&h[(unsigned)(k >> shift) & 255u][lane], 1u);
+    };
+    long long r = r0 + wave;
+    for (; r + 28 < r1; r += 32) {  // eight rows in flight per lane: the sampled rows are far apart, each a fresh HBM line
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = y[sample_row(r + 4 * u, stride) * M + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) count(v[u]);
     }
+    for (; r < r1; r += 4) count(y[sample_row(r, stride) * M + col]);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 256 * 64; i += 256) {
