@@ -87,11 +87,19 @@ __device__ double block_select(Get get, long long n, long long k, unsigned* hist
     const int shift = 56 - 8 * pass;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0u;
     __syncthreads();
-    for (long long i0 = 0; i0 < n; i0 += blockDim.x) {  // uniform trip count: hist_add uses wave-wide votes
-      const long long i = i0 + threadIdx.x;
-      const unsigned long long key = (i < n) ? dkey(get(i)) : 0ull;
-      const bool in = (i < n) && (pass == first_pass || (key >> (shift + 8)) == (prefix >> (shift + 8)));
-      hist_add(hist, (unsigned)(key >> shift) & 255u, in);
+    for (long long i0 = 0; i0 < n; i0 += 4ll * blockDim.x) {  // uniform trip count: hist_add uses wave-wide votes
+      unsigned long long key[4];
+      bool in[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // four values in flight per thread
+        const long long i = i0 + (long long)u * blockDim.x + threadIdx.x;
+        in[u] = i < n;
+        key[u] = in[u] ? dkey(get(i)) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        hist_add(hist, (unsigned)(key[u] >> shift) & 255u,
+                 in[u] && (pass == first_pass || (key[u] >> (shift + 8)) == (prefix >> (shift + 8))));
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -580,7 +588,17 @@ __global__ void __launch_bounds__(BT) pdw_tilescan_kernel(int M, long long ntile
   const long long t0 = (long long)tid * per < ntiles ? (long long)tid * per : ntiles;
   const long long t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
   int f = 0x2;  // identity: f(0)=0, f(1)=1  -> bits (f0 | f1<<1) = 0b10
-  for (long long t = t0; t < t1; ++t) f = compose_fn(f, fn[t * M + col]);
+  {
+    long long t = t0;
+    for (; t + 8 <= t1; t += 8) {  // eight loads in flight: the chain through f is cheap, the strided bytes are not
+      int g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g[u] = fn[(t + u) * M + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) f = compose_fn(f, g[u]);
+    }
+    for (; t < t1; ++t) f = compose_fn(f, fn[t * M + col]);
+  }
   // inclusive scan of function composition across the wave, then across waves
   int inc = f;
   for (int d = 1; d < 64; d <<= 1) {
@@ -599,12 +617,23 @@ __global__ void __launch_bounds__(BT) pdw_tilescan_kernel(int M, long long ntile
   const int s_in = exc & 1;  // state entering my segment when the stream starts inactive: exc(0)
   int s = s_in;
   unsigned long long a = 0, b = 0;
-  for (long long t = t0; t < t1; ++t) {
-    state_in[t * M + col] = (unsigned char)s;
-    const ushort4 c = cnt[t * M + col];
-    a += s ? c.z : c.x;
-    b += s ? c.w : c.y;
-    s = (fn[t * M + col] >> s) & 1;
+  {
+    auto step = [&](long long t, ushort4 c, int g) {
+      state_in[t * M + col] = (unsigned char)s;
+      a += s ? c.z : c.x;
+      b += s ? c.w : c.y;
+      s = (g >> s) & 1;
+    };
+    long long t = t0;
+    for (; t + 8 <= t1; t += 8) {
+      ushort4 c[8];
+      int g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { c[u] = cnt[(t + u) * M + col]; g[u] = fn[(t + u) * M + col]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) step(t + u, c[u], g[u]);
+    }
+    for (; t < t1; ++t) step(t, cnt[t * M + col], fn[t * M + col]);
   }
   unsigned long long ia = a, ib = b;
   for (int d = 1; d < 64; d <<= 1) {
@@ -620,12 +649,23 @@ __global__ void __launch_bounds__(BT) pdw_tilescan_kernel(int M, long long ntile
   }
   unsigned long long ea = ia - a, eb = ib - b;  // exclusive
   s = s_in;
-  for (long long t = t0; t < t1; ++t) {
-    off_s[t * M + col] = ea; off_e[t * M + col] = eb;
-    const ushort4 c = cnt[t * M + col];
-    ea += s ? c.z : c.x;
-    eb += s ? c.w : c.y;
-    s = (fn[t * M + col] >> s) & 1;
+  {
+    auto step = [&](long long t, ushort4 c, int g) {
+      off_s[t * M + col] = ea; off_e[t * M + col] = eb;
+      ea += s ? c.z : c.x;
+      eb += s ? c.w : c.y;
+      s = (g >> s) & 1;
+    };
+    long long t = t0;
+    for (; t + 8 <= t1; t += 8) {
+      ushort4 c[8];
+      int g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { c[u] = cnt[(t + u) * M + col]; g[u] = fn[(t + u) * M + col]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) step(t + u, c[u], g[u]);
+    }
+    for (; t < t1; ++t) step(t, cnt[t * M + col], fn[t * M + col]);
   }
   if (tid == BT - 1) { tot_s[col] = ia; tot_e[col] = ib; }
 }
