@@ -184,6 +184,8 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
         if (h->opt_frames_per_block <= 0) fpb = 64;
         if (h->opt_xcd_remap < 0) p.xcd_remap = 0;  // 512-frame workgroups: one dense sweep beats L2 halo hits
       }
+      // short sliding runs in dispatch order already sweep the stream as one window: leave them round-robin over the XCDs
+      if (p.schedule == 0 && fpb <= 64 && h->opt_xcd_remap < 0) p.xcd_remap = 0;
       p.frames_per_block = fpb;
       const int cpt = h->fast->cols_per_thread;
       const int bmod = ((p.base % cpt) + cpt) % cpt;
