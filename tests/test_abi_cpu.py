@@ -85,3 +85,31 @@ def test_product_sources_do_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".c")):
                 text = open(os.path.join(base, f), errors="ignore").read()
                 assert "pfb_oracle" not in text and "pfbo_" not in text and "from oracle" not in text, f
+
+
+def test_fft_plan_model_covers_the_registered_plans():
+    """tools/fft_plan_model.py is the executable statement of the LDS layout formulas (pos_i, twiddles, digit order)
+    the fused kernels use: every plan registered in pfb_kernels.hip must reproduce numpy's inverse-type DFT."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fft_plan_model", os.path.join(root, "tools", "fft_plan_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(3)
+    modelled = set()
+    for name, (M, R, RS, FS, C, NT) in m.PLANS.items():
+        x = rng.standard_normal(M) + 1j * rng.standard_normal(M)
+        y = m.run_plan(x, R, RS)
+        ref = np.fft.ifft(x) * M
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-12, name
+        assert max(R[i] * RS[i] for i in range(len(R))) <= FS, name
+        modelled.add((M, tuple(R), tuple(RS), FS))
+    # every FastCfg<...> in the kernel table has its (M, radices, row strides, frame stride) in the model
+    src = open(os.path.join(root, "sdr_channelizer_amd", "csrc", "pfb_kernels.hip")).read()
+    for args in re.findall(r"FastCfg<([^>]*)>", src):
+        a = [t.strip() for t in args.split(",")]
+        M, NP = int(a[0]), int(a[6])
+        R = tuple(int(v) for v in a[7:7 + NP])
+        RS = tuple(int(v) for v in a[10:10 + NP])
+        assert (M, R, RS, int(a[13])) in modelled, args
