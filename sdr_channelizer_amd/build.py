@@ -15,8 +15,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libpfb_channelizer.so")
-SOURCES = ["pfb_api.cpp", "pfb_kernels.hip", "pfb_pdw.hip", "iq_packet.c"]
-HEADERS = ["pfb_common.h", "pfb_fast.hpp"]
+SOURCES = ["pfb_api.cpp", "pfb_kernels.hip", "pfb_kernels_mid.hip", "pfb_kernels_big.hip", "pfb_pdw.hip", "iq_packet.c"]
+HEADERS = ["pfb_common.h", "pfb_fast.hpp", "pfb_table.h"]
 ARCH = "gfx950"
 
 
@@ -44,6 +44,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     bdir = os.path.join(PKG, "build")
     os.makedirs(bdir, exist_ok=True)
     common = ["-O3", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+    jobs = []
     for src in SOURCES:
         obj = os.path.join(bdir, src + ".o")
         path = os.path.join(CSRC, src)
@@ -51,10 +52,18 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
             cmd = [hipcc, "-x", "c", "-std=c11"] + common + ["-c", path, "-o", obj]
         else:
             cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-std=c++20"] + common + ["-c", path, "-o", obj]
+        jobs.append(cmd)
+        objs.append(obj)
+
+    def compile_one(cmd):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-        objs.append(obj)
+
+    # the kernel translation units dominate (tens of seconds each): compile them side by side
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+        list(pool.map(compile_one, jobs))
     tmp = LIB + ".tmp"
     subprocess.check_call([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp] + objs)
     os.replace(tmp, LIB)

@@ -11,7 +11,7 @@
 //                          (the dsp.Channelizer System-object state,
 //                          channelizer_example.m:50-56)
 //   pfb_stream_copy        1 read : 2 write streaming copy, the measured-HBM yardstick
-#include "pfb_fast.hpp"
+#include "pfb_table.h"
 
 namespace pfb {
 
@@ -188,90 +188,28 @@ hipError_t launch_stream_copy(const void* in, void* out, long long n_vec16, hipS
 }
 
 // ---------------------------------------------------------------------------------
-// fast kernel table
-//                 M    P   D  CPT FMT               C NP R0 R1 R2 RS0 RS1 RS2 FS  PP     MINW
+// fused-kernel table, part 1: the M = 64 shapes (cfg2 and its int8 / cf32 siblings)
+//                 M    P   D  CPT FMT               C NP R0 R1 R2 RS0 RS1 RS2 FS  PP     MINW  TW_TABLE
 using Cfg64x12i16 = FastCfg<64, 12, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
 using Cfg64x12i8  = FastCfg<64, 12, 64, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
 using Cfg64x12f32 = FastCfg<64, 12, 64, 1, PFB_FMT_CF32,     8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
-// cfg5: 2x oversampled, 24 taps per column, 128 = 16 x 8 (final-pass LDS reads are 2-way conflicted:
-// no single frame stride serves both passes, tools/fft_plan_model.py); schedule 7 (6 FIR/FFT wave pairs per
-// workgroup) measured within noise of one wave doing both (+0..3 %), so the default stays schedule 0
-using Cfg128x12os2i16 = FastCfg<128, 12, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 16, 8, 1, 8, 17, 0, 136, false, 2>;
-// cfg3: 4 adjacent columns per lane (8-byte loads of int8 I/Q), 256 = 16 x 16, conflict-free; short sliding runs (32
-// frames, 22 % more row reads of a stream that is 80 % writes) keep the chip's active window small: +4 % over 256
-using Cfg256x8i8  = FastCfg<256, 8, 256, 4, PFB_FMT_INT8_IQ,  4, 2, 16, 16, 1, 16, 17, 0, 272, false, 2>;
-using Cfg256x8i16 = FastCfg<256, 8, 256, 4, PFB_FMT_INT16_IQ, 4, 2, 16, 16, 1, 16, 17, 0, 272, false, 2>;
 
-// cfg4: 512 threads x 2 adjacent columns (8-byte loads), 1024 = 16 x 16 x 4 in place in one 68 KB chunk
-// buffer (read - barrier - write), twiddles from the L1-resident table, conflict-free padding
-using Cfg1024x16i16 =
-    FastCfg<1024, 16, 1024, 2, PFB_FMT_INT16_IQ, 8, 3, 16, 16, 4, 64, 68, 260, 1088, false, 2, true>;
-
-// cfg4, second plan: 1024 threads x 1 column (16 waves per CU instead of 8: the window is half as many
-// registers per thread), 1024 = 8 x 8 x 16, conflict-free padding
-using Cfg1024x16i16b =
-    FastCfg<1024, 16, 1024, 1, PFB_FMT_INT16_IQ, 8, 3, 8, 8, 16, 128, 128, 65, 1040, false, 1, true>;
-
-
-
-// the reference's own band count: numBands = fs*1e-6 = 56 (channelizer_example.m:29, generate_pulsed_iq.m:12),
-// 56 = 8 x 7; 56 of the wave's 64 lanes own columns (2-way LDS conflicts on about half the accesses); default
-// schedule 7 (8 FIR/FFT wave pairs per workgroup over sliding runs of 512 frames, +17 %)
-using Cfg56x12i16 = FastCfg<56, 12, 56, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
-using Cfg56x12i8  = FastCfg<56, 12, 56, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
-
-// the reference's training-set band count: numBands = round(fs / 0.1e6) = 560 at fs = 56 MHz
-// (generate_channelized_training_iq.m:95-96).  560 = 10 x 8 x 7; 560 of 576 threads own columns; chunks
-// of 7 frames make every pass one iteration (7 * 80 = 560 final-pass items); at most 2-way LDS conflicts
-// on about a third of the accesses (no padding removes them for this size, tools/fft_plan_model.py)
-using Cfg560x12i16 =
-    FastCfg<560, 12, 560, 1, PFB_FMT_INT16_IQ, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;
-using Cfg560x12i8 =
-    FastCfg<560, 12, 560, 1, PFB_FMT_INT8_IQ, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;// cfg4, team plan (the default): 512 FIR threads x 2 columns filter chunks of 4 frames and run the last pass
-// + stores of the chunk before the previous one; 4 FFT waves take one frame each for the first two passes
-// (16 x 16 x 4, wave-local, twiddles in registers); 12 waves per workgroup, three LDS chunk buffers, one
-// workgroup barrier per chunk (pfb_fast.hpp, schedule T)
-using Cfg1024x16i16t =
-    FastCfg<1024, 16, 1024, 2, PFB_FMT_INT16_IQ, 4, 3, 16, 16, 4, 64, 68, 260, 1088, false, 3, false>;
-// M = 560, team plan (the default): 280 FIR threads x 2 columns (5 waves) + 4 FFT waves, chunks of 4 frames,
-// 560 = 14 x 10 x 4 so that both FFT-team passes are one item per lane (40 and 56 of 64 lanes; with 10 x 8 x 7 the
-// second pass needed two iterations and the FFT team was the bottleneck: 1.00 -> 0.83-0.87 ms)
-using Cfg560x12i16t =
-    FastCfg<560, 12, 560, 2, PFB_FMT_INT16_IQ, 4, 3, 14, 10, 4, 40, 60, 140, 600, false, 3, false>;
-using Cfg560x12i8t =
-    FastCfg<560, 12, 560, 2, PFB_FMT_INT8_IQ, 4, 3, 14, 10, 4, 40, 60, 140, 600, false, 3, false>;
-
-struct FastEntry { int M, P, D, fmt; FastKernelInfo info; };
-
-template <class K>
-constexpr FastEntry entry(const char* name, int default_fpb, int default_schedule) {
-  return FastEntry{K::M, K::P, K::D, K::FMT,
-                   FastKernelInfo{&launch_fast<K>, &init_tables<K>, K::TAPS_LANE_FLOATS, K::TW_LANE_ELEMS, name, K::C,
-                                  default_fpb, K::CPT, default_schedule, kChannelMajorOk<K>}};
-}
-
-static const FastEntry kFastTable[] = {
+static const FastEntry kRows[] = {
     entry<Cfg64x12i16>("pfb_fast<M64,P12,D64,int16>", 512, 4),
     entry<Cfg64x12i8>("pfb_fast<M64,P12,D64,int8>", 256, 7),  // 8-bit rows are half as long: pairs over long runs beat the shared-halo tiles by 10 %
     entry<Cfg64x12f32>("pfb_fast<M64,P12,D64,cf32>", 512, 4),
-    entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 512, 0),
-    entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 32, 0),
-    entry<Cfg256x8i16>("pfb_fast<M256,P8,D256,int16>", 32, 0),
-    entry<Cfg1024x16i16t>("pfb_fast<M1024,P16,D1024,int16>", 512, 6),
-    entry<Cfg1024x16i16b>("pfb_fast<M1024,P16,D1024,int16,16w>", 256, 0),
-    entry<Cfg1024x16i16>("pfb_fast<M1024,P16,D1024,int16,8w>", 256, 0),
-    entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 7),
-    entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 7),
-    entry<Cfg560x12i16t>("pfb_fast<M560,P12,D560,int16>", 512, 6),
-    entry<Cfg560x12i8t>("pfb_fast<M560,P12,D560,int8>", 512, 6),
-    entry<Cfg560x12i16>("pfb_fast<M560,P12,D560,int16,9w>", 252, 0),
-    entry<Cfg560x12i8>("pfb_fast<M560,P12,D560,int8,9w>", 252, 0),
 };
 
+FastTablePart fast_table_m64() { return FastTablePart{kRows, (int)(sizeof(kRows) / sizeof(kRows[0]))}; }
+
 const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant, bool channel_major) {
-  for (const FastEntry& e : kFastTable)
-    if (e.M == M && e.P == P && e.D == D && e.fmt == fmt && (!channel_major || e.info.channel_major_ok) && variant-- == 0)
-      return &e.info;
+  const FastTablePart parts[] = {fast_table_m64(), fast_table_mid(), fast_table_big()};
+  for (const FastTablePart& part : parts)
+    for (int i = 0; i < part.count; ++i) {
+      const FastEntry& e = part.rows[i];
+      if (e.M == M && e.P == P && e.D == D && e.fmt == fmt && (!channel_major || e.info.channel_major_ok) && variant-- == 0)
+        return &e.info;
+    }
   return nullptr;
 }
 

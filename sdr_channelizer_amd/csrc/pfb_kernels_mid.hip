@@ -1,0 +1,49 @@
+// pfb_kernels_mid.hip -- fused-kernel table, part 2: the other single-wave shapes (cfg3, cfg5, M = 56, the small banks) (see pfb_table.h)
+#include <hip/hip_runtime.h>
+
+#include "pfb_table.h"
+
+namespace pfb {
+
+//                 M    P   D  CPT FMT               C NP R0 R1 R2 RS0 RS1 RS2 FS  PP     MINW  TW_TABLE
+// cfg5: 2x oversampled, 24 taps per column, 128 = 16 x 8 (final-pass LDS reads are 2-way conflicted:
+// no single frame stride serves both passes, tools/fft_plan_model.py); schedule 7 (6 FIR/FFT wave pairs per
+// workgroup) measured within noise of one wave doing both (+0..3 %), so the default stays schedule 0
+using Cfg128x12os2i16 = FastCfg<128, 12, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 16, 8, 1, 8, 17, 0, 136, false, 2>;
+// cfg3: 4 adjacent columns per lane (8-byte loads of int8 I/Q), 256 = 16 x 16, conflict-free; short sliding runs (32
+// frames, 22 % more row reads of a stream that is 80 % writes) keep the chip's active window small: +4 % over 256
+using Cfg256x8i8  = FastCfg<256, 8, 256, 4, PFB_FMT_INT8_IQ,  4, 2, 16, 16, 1, 16, 17, 0, 272, false, 2>;
+using Cfg256x8i16 = FastCfg<256, 8, 256, 4, PFB_FMT_INT16_IQ, 4, 2, 16, 16, 1, 16, 17, 0, 272, false, 2>;
+// the reference's own band count: numBands = fs*1e-6 = 56 (channelizer_example.m:29, generate_pulsed_iq.m:12),
+// 56 = 8 x 7; 56 of the wave's 64 lanes own columns (2-way LDS conflicts on about half the accesses); default
+// schedule 7 (8 FIR/FFT wave pairs per workgroup over sliding runs of 512 frames, +17 %)
+using Cfg56x12i16 = FastCfg<56, 12, 56, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
+using Cfg56x12i8  = FastCfg<56, 12, 56, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
+// small banks (numBands = fs * 1e-6 at 8 / 16 / 32 Msps, channelizer_example.m:29): M of the wave's 64 lanes own
+// columns, the rest idle through the FIR; still an order of magnitude ahead of the generic kernel
+using Cfg32x12i16 = FastCfg<32, 12, 32, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 4, 1, 4, 9, 0, 36, false, 4>;
+using Cfg16x12i16 = FastCfg<16, 12, 16, 1, PFB_FMT_INT16_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, false, 4>;
+using Cfg8x12i16 = FastCfg<8, 12, 8, 1, PFB_FMT_INT16_IQ, 8, 2, 2, 4, 1, 4, 3, 0, 12, false, 4>;
+using Cfg32x12i8 = FastCfg<32, 12, 32, 1, PFB_FMT_INT8_IQ, 8, 2, 8, 4, 1, 4, 9, 0, 36, false, 4>;
+using Cfg16x12i8 = FastCfg<16, 12, 16, 1, PFB_FMT_INT8_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, false, 4>;
+using Cfg8x12i8 = FastCfg<8, 12, 8, 1, PFB_FMT_INT8_IQ, 8, 2, 2, 4, 1, 4, 3, 0, 12, false, 4>;
+using Cfg8x12f32 = FastCfg<8, 12, 8, 1, PFB_FMT_CF32, 8, 2, 2, 4, 1, 4, 3, 0, 12, false, 4>;  // cfg1's own shape and format
+
+static const FastEntry kRows[] = {
+    entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 512, 0),
+    entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 32, 0),
+    entry<Cfg256x8i16>("pfb_fast<M256,P8,D256,int16>", 32, 0),
+    entry<Cfg32x12i16>("pfb_fast<M32,P12,D32,int16>", 512, 0),
+    entry<Cfg16x12i16>("pfb_fast<M16,P12,D16,int16>", 512, 0),
+    entry<Cfg8x12i16>("pfb_fast<M8,P12,D8,int16>", 512, 0),
+    entry<Cfg32x12i8>("pfb_fast<M32,P12,D32,int8>", 512, 0),
+    entry<Cfg16x12i8>("pfb_fast<M16,P12,D16,int8>", 512, 0),
+    entry<Cfg8x12i8>("pfb_fast<M8,P12,D8,int8>", 512, 0),
+    entry<Cfg8x12f32>("pfb_fast<M8,P12,D8,cf32>", 512, 0),
+    entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 7),
+    entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 7),
+};
+
+FastTablePart fast_table_mid() { return FastTablePart{kRows, (int)(sizeof(kRows) / sizeof(kRows[0]))}; }
+
+}  // namespace pfb

@@ -1,0 +1,23 @@
+// pfb_table.h -- one row of the fused-kernel table; the table is split over three translation units
+// (pfb_kernels.hip: M = 64; pfb_kernels_mid.hip: the other single-wave shapes; pfb_kernels_big.hip: M = 1024 and
+// 560) so that they compile in parallel.
+#pragma once
+#include "pfb_fast.hpp"
+
+namespace pfb {
+
+struct FastEntry { int M, P, D, fmt; FastKernelInfo info; };
+
+template <class K>
+constexpr FastEntry entry(const char* name, int default_fpb, int default_schedule) {
+  return FastEntry{K::M, K::P, K::D, K::FMT,
+                   FastKernelInfo{&launch_fast<K>, &init_tables<K>, K::TAPS_LANE_FLOATS, K::TW_LANE_ELEMS, name, K::C,
+                                  default_fpb, K::CPT, default_schedule, kChannelMajorOk<K>}};
+}
+
+struct FastTablePart { const FastEntry* rows; int count; };
+FastTablePart fast_table_m64();
+FastTablePart fast_table_mid();
+FastTablePart fast_table_big();
+
+}  // namespace pfb

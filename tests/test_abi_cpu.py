@@ -106,7 +106,9 @@ def test_fft_plan_model_covers_the_registered_plans():
         assert max(R[i] * RS[i] for i in range(len(R))) <= FS, name
         modelled.add((M, tuple(R), tuple(RS), FS))
     # every FastCfg<...> in the kernel table has its (M, radices, row strides, frame stride) in the model
-    src = open(os.path.join(root, "sdr_channelizer_amd", "csrc", "pfb_kernels.hip")).read()
+    csrc = os.path.join(root, "sdr_channelizer_amd", "csrc")
+    src = "".join(open(os.path.join(csrc, f)).read() for f in ("pfb_kernels.hip", "pfb_kernels_mid.hip", "pfb_kernels_big.hip"))
+    assert src.count("FastCfg<") >= 20
     for args in re.findall(r"FastCfg<([^>]*)>", src):
         a = [t.strip() for t in args.split(",")]
         M, NP = int(a[0]), int(a[6])

@@ -58,7 +58,8 @@ def test_cfg2_uses_the_fast_kernel(golden_dir):
 @pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (64, 12, 64, "int8", 8), (256, 8, 256, "int8", 8),
                                           (128, 12, 64, "int16", 12), (1024, 16, 1024, "int16", 16),
                                           (56, 12, 56, "int16", 12), (8, 12, 8, "int16", 12),
-                                          (560, 12, 560, "int16", 12), (560, 12, 560, "int8", 8), (56, 12, 56, "int8", 8)])
+                                          (560, 12, 560, "int16", 12), (560, 12, 560, "int8", 8), (56, 12, 56, "int8", 8),
+                                          (32, 12, 32, "int16", 12), (16, 12, 16, "int16", 12)])
 @pytest.mark.parametrize("q0", [0, 3])
 def test_one_hot_tap_bit_exact(M, P, D, fmt, bw, q0):
     """h = delta[n - M q0] => every channel of frame m equals x[mD + D-1 - M q0] exactly:
@@ -83,7 +84,7 @@ def test_one_hot_tap_bit_exact(M, P, D, fmt, bw, q0):
     (256, 8, 256, "int8", 8, 1 << 17), (128, 12, 64, "int16", 12, 1 << 16), (1024, 16, 1024, "int16", 16, 1 << 18),
     (32, 12, 32, "int16", 12, 1 << 14), (16, 4, 8, "int16", 16, 1 << 12), (56, 12, 56, "int16", 12, 56 * 300),
     (12, 5, 4, "int8", 8, 4 * 500), (560, 12, 560, "int16", 12, 560 * 150 + 31), (560, 12, 560, "int8", 8, 560 * 64),
-    (56, 12, 56, "int8", 8, 56 * 1500 + 3)])
+    (56, 12, 56, "int8", 8, 56 * 1500 + 3), (16, 12, 16, "int16", 12, 16 * 4000 + 9), (8, 12, 8, "int16", 12, 8 * 9000 + 3)])
 def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     rng = np.random.default_rng(n + M)
     if fmt == "cf32":
@@ -97,7 +98,7 @@ def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     assert rel(y, want) < REL_TOL
 
 
-@pytest.mark.parametrize("M,P,D", [(64, 12, 64), (128, 12, 64), (56, 12, 56), (560, 12, 560)])
+@pytest.mark.parametrize("M,P,D", [(64, 12, 64), (128, 12, 64), (56, 12, 56), (560, 12, 560), (32, 12, 32), (8, 12, 8)])
 @pytest.mark.parametrize("kw", [dict(fftshift=True), dict(conjugate_input=True), dict(derotate=True),
                                 dict(input_offset=0), dict(input_offset=5),
                                 dict(fftshift=True, conjugate_input=True, derotate=True)])
@@ -153,7 +154,7 @@ def test_channel_major_device_path_is_bit_identical_to_frame_major():
 
 
 @pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (128, 12, 64, "int16", 12), (56, 12, 56, "int16", 12),
-                                          (256, 8, 256, "int8", 8), (560, 12, 560, "int16", 12)])
+                                          (256, 8, 256, "int8", 8), (560, 12, 560, "int16", 12), (16, 12, 16, "int16", 12)])
 def test_chunked_equals_one_shot_bit_exact(M, P, D, fmt, bw):
     """The handle is stateful like the System object (channelizer_example.m:50-56): any split of
     the stream -- including pieces that are not multiples of D -- gives identical bits."""

@@ -113,6 +113,9 @@ PLANS = {
     "m56": (56, [8, 7], [7, 9], 71, 8, 64),           # the reference's fs*1e-6; 2-way on ~half the accesses
     "m560_9w": (560, [10, 8, 7], [56, 71, 82], 600, 7, 576),     # round(fs/0.1e6); 2-way on ~a third
     "m560_teams": (560, [14, 10, 4], [40, 60, 140], 600, 4, 320),
+    "m32": (32, [8, 4], [4, 9], 36, 8, 64),
+    "m16": (16, [4, 4], [4, 5], 20, 8, 64),
+    "m8": (8, [2, 4], [4, 3], 12, 8, 64),
 }
 
 if __name__ == "__main__":
