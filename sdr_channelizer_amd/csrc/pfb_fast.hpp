@@ -1280,6 +1280,174 @@ struct FastKernel {
   }
 };
 
+// ---------------------------------------------------------------------------------
+// Small banks (M = 8, 16, 32: numBands = fs * 1e-6 at 8 ... 32 Msps).  With one column per lane only M of the
+// wave's 64 lanes would filter.  Here the workgroup's run of frames is cut into SEG = 64 / M contiguous
+// segments and lane (seg, col) slides column col's window over segment seg: all 64 lanes filter, a chunk is
+// C * SEG frames, and the two FFT passes run over all of them (ping-pong LDS buffers, twiddles from the table).
+// Same tables, same arithmetic per output as FastKernel; critically sampled, two-pass plans only.
+template <class K>
+struct SegKernel {
+  using ST = SampleT<K::FMT>;
+  using raw_t = typename ST::raw_t;
+  static constexpr int M = K::M, P = K::P, D = K::D, C = K::C, W = K::W;
+  static constexpr int SEG = 64 / M, CT = C * SEG, NW = W - 1 + C;
+  static_assert(K::NT == 64 && K::CPT == 1 && K::OS == 1 && K::NP == 2 && K::PINGPONG && 64 % M == 0 && SEG >= 2, "small banks");
+
+  PFB_DEV v2f cvt(raw_t r) {
+    float re, im;
+    ST::cvt(r, re, im);
+    return (v2f){re, im};
+  }
+
+  // sample `s` of the stream (index relative to this call's buffer; negative = history), row of frame `f`
+  template <bool INTERIOR>
+  PFB_DEV raw_t load(const KernelParams& p, long long s, long long f) {
+    const raw_t* in = static_cast<const raw_t*>(p.in);
+    if constexpr (INTERIOR) {
+      return in[s];
+    } else {
+      if (f >= p.frames) return raw_t{};
+      return (s >= 0) ? in[s] : static_cast<const raw_t*>(p.hist)[p.hist_samples + s];
+    }
+  }
+
+  template <int I>
+  PFB_DEV void pass(const KernelParams& p, const float2* src, float2* dst, int tid, long long f_begin, long long l_seg,
+                    long long chunk0) {
+    constexpr int R = K::R(I), S = K::S(I), KK = K::K(I), RS = K::RS(I);
+    constexpr int IPF = M / R, ITEMS = CT * IPF, ITERS = (ITEMS + 63) / 64;
+    constexpr bool LAST = (I == 1);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int w = tid + it * 64;
+      const bool active = (ITEMS % 64 == 0) || (w < ITEMS);
+      const int fc = active ? w / IPF : 0, item = active ? w % IPF : 0;
+      const int kk = item / S, rest = item % S;
+      v2f x[R];
+      const v2f* s2 = reinterpret_cast<const v2f*>(src) + fc * K::FS + item;
+#pragma unroll
+      for (int n = 0; n < R; ++n) x[n] = s2[n * RS];
+      Dft<R>::run(x);
+      if constexpr (!LAST) {
+        constexpr int S1 = K::S(I + 1), RS1 = K::RS(I + 1);
+        const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(I) + rest * R);
+#pragma unroll
+        for (int k2 = 0; k2 < R / 2; ++k2) {
+          const float4 t = t4[k2];
+          if (k2 > 0) x[2 * k2] = cmul_w(x[2 * k2], (v2f){t.x, t.y});
+          x[2 * k2 + 1] = cmul_w(x[2 * k2 + 1], (v2f){t.z, t.w});
+        }
+        if (active) {
+          const int n1 = rest / S1, rest2 = rest % S1;
+          v2f* d2 = reinterpret_cast<v2f*>(dst) + fc * K::FS + n1 * RS1 + kk * S1 + rest2;
+#pragma unroll
+          for (int k = 0; k < R; ++k) d2[k * KK * S1] = x[k];
+        }
+      } else {
+        const long long f = f_begin + (fc / C) * l_seg + chunk0 + (fc % C);  // frame (segment fc / C, chunk, t)
+        if (active && f < p.frames) {
+          const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
+          const bool mag = (p.flags & PFB_FLAG_MAGNITUDE) != 0, cm = p.layout == PFB_LAYOUT_CHANNEL_MAJOR;
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            int col = kk + k * KK + shift;
+            col = col >= M ? col - M : col;
+            const long long o = cm ? (long long)col * p.out_ld + p.out_frame0 + f : f * M + col;
+            if (mag) reinterpret_cast<float*>(p.out)[o] = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
+            else store_c64(&p.out[o], x[k], p.nontemporal);
+          }
+        }
+      }
+    }
+  }
+
+  template <bool INTERIOR>
+  PFB_DEV void run_impl(const KernelParams& p, float2* lds, long long f_begin, long long l_seg) {
+    const int tid = threadIdx.x, seg = tid / M, col = tid % M;
+    const long long f_seg = f_begin + seg * l_seg;                  // my segment's first frame
+    const long long s_row0 = (f_seg - (W - 1)) * D + p.base + col;  // my column in the first halo row
+    // taps of my column, two per register pair (the same table FastKernel::setup reads)
+    v2f hp[(W + 1) / 2];
+    {
+      const float4* tl = reinterpret_cast<const float4*>(p.taps_lane + (size_t)col * K::WP);
+#pragma unroll
+      for (int q4 = 0; q4 < K::WP / 4; ++q4) {
+        const float4 v = tl[q4];
+        if (2 * q4 < (W + 1) / 2) hp[2 * q4] = (v2f){v.x, v.y};
+        if (2 * q4 + 1 < (W + 1) / 2) hp[2 * q4 + 1] = (v2f){v.z, v.w};
+      }
+    }
+    const v2f conj_mul = (v2f){1.f, (p.flags & PFB_FLAG_CONJUGATE_INPUT) ? -1.f : 1.f};
+    const int n = D - 1 - col;  // my branch
+    const int upos = (n / K::S(0)) * K::RS(0) + (n % K::S(0));
+    float2* buf0 = lds;
+    float2* buf1 = lds + CT * K::FS;
+    v2f x[NW];
+    raw_t raw[C];
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) x[i] = cvt(load<INTERIOR>(p, s_row0 + (long long)i * D, f_seg - (W - 1) + i));
+#pragma unroll
+    for (int t = 0; t < C; ++t) raw[t] = load<INTERIOR>(p, s_row0 + (long long)(W - 1 + t) * D, f_seg + t);
+    for (long long c0 = 0; c0 < l_seg; c0 += C) {
+#pragma unroll
+      for (int t = 0; t < C; ++t) x[W - 1 + t] = cvt(raw[t]);
+      if (c0 + C < l_seg) {
+#pragma unroll
+        for (int t = 0; t < C; ++t)
+          raw[t] = load<INTERIOR>(p, s_row0 + (c0 + C + (W - 1) + t) * D, f_seg + c0 + C + t);
+      }
+      v2f acc[C];
+#pragma unroll
+      for (int t = 0; t < C; ++t) acc[t] = (v2f){0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+          if (q & 1) fma_tap_hi(acc[t], x[W - 1 + t - q], hp[q >> 1]);
+          else fma_tap_lo(acc[t], x[W - 1 + t - q], hp[q >> 1]);
+        }
+#pragma unroll
+      for (int t = 0; t < C; ++t) reinterpret_cast<v2f*>(buf0)[(seg * C + t) * K::FS + upos] = acc[t] * conj_mul;
+      team_sync<true>();
+      pass<0>(p, buf0, buf1, tid, f_begin, l_seg, c0);
+      team_sync<true>();
+      pass<1>(p, buf1, nullptr, tid, f_begin, l_seg, c0);
+      team_sync<true>();
+#pragma unroll
+      for (int i = 0; i < W - 1; ++i) x[i] = x[i + C];
+    }
+  }
+
+  PFB_DEV void run(const KernelParams& p, float2* lds) {
+    long long run = blockIdx.x;
+    if (p.xcd_remap) {
+      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
+      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
+    }
+    const long long f_begin = run * p.frames_per_block;
+    if (f_begin >= p.frames) return;
+    const long long l_seg = p.frames_per_block / SEG;  // host rounds frames_per_block to a multiple of C * SEG
+    const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_begin + p.frames_per_block <= p.frames);
+    if (interior) run_impl<true>(p, lds, f_begin, l_seg);
+    else run_impl<false>(p, lds, f_begin, l_seg);
+  }
+};
+
+template <class K>
+__global__ void __launch_bounds__(64, K::MIN_WAVES) pfb_seg_kernel(const KernelParams p) {
+  __shared__ float2 lds[2 * SegKernel<K>::CT * K::FS];
+  SegKernel<K>::run(p, lds);
+}
+
+template <class K>
+hipError_t launch_seg(const KernelParams& p, hipStream_t s) {
+  if (p.frames <= 0) return hipSuccess;
+  const long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
+  hipLaunchKernelGGL(pfb_seg_kernel<K>, dim3((unsigned)nb), dim3(64), 0, s, p);
+  return hipGetLastError();
+}
+
 // Builds the per-column tap table and the inter-pass twiddle rows (once per handle).
 template <class K>
 __global__ void __launch_bounds__(256) pfb_init_tables_kernel(const float* taps, const float2* tw, float* taps_lane,

@@ -19,27 +19,28 @@ using Cfg256x8i16 = FastCfg<256, 8, 256, 4, PFB_FMT_INT16_IQ, 4, 2, 16, 16, 1, 1
 // schedule 7 (8 FIR/FFT wave pairs per workgroup over sliding runs of 512 frames, +17 %)
 using Cfg56x12i16 = FastCfg<56, 12, 56, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
 using Cfg56x12i8  = FastCfg<56, 12, 56, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
-// small banks (numBands = fs * 1e-6 at 8 / 16 / 32 Msps, channelizer_example.m:29): M of the wave's 64 lanes own
-// columns, the rest idle through the FIR; still an order of magnitude ahead of the generic kernel
+// small banks (numBands = fs * 1e-6 at 8 / 16 / 32 Msps, channelizer_example.m:29).  M = 32: the ordinary kernel with
+// half the lanes idle through the FIR (52 %; two segments per wave measured 47 %).  M = 16 and 8: SegKernel, 64 / M
+// segments of the run per wave so that every lane filters (36 -> 49 %, 24 -> 40 %); ping-pong LDS buffers (PP = true)
 using Cfg32x12i16 = FastCfg<32, 12, 32, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 4, 1, 4, 9, 0, 36, false, 4>;
-using Cfg16x12i16 = FastCfg<16, 12, 16, 1, PFB_FMT_INT16_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, false, 4>;
-using Cfg8x12i16 = FastCfg<8, 12, 8, 1, PFB_FMT_INT16_IQ, 8, 2, 2, 4, 1, 4, 3, 0, 12, false, 4>;
+using Cfg16x12i16 = FastCfg<16, 12, 16, 1, PFB_FMT_INT16_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, true, 4>;
+using Cfg8x12i16 = FastCfg<8, 12, 8, 1, PFB_FMT_INT16_IQ, 8, 2, 2, 4, 1, 4, 3, 0, 12, true, 4>;
 using Cfg32x12i8 = FastCfg<32, 12, 32, 1, PFB_FMT_INT8_IQ, 8, 2, 8, 4, 1, 4, 9, 0, 36, false, 4>;
-using Cfg16x12i8 = FastCfg<16, 12, 16, 1, PFB_FMT_INT8_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, false, 4>;
-using Cfg8x12i8 = FastCfg<8, 12, 8, 1, PFB_FMT_INT8_IQ, 8, 2, 2, 4, 1, 4, 3, 0, 12, false, 4>;
-using Cfg8x12f32 = FastCfg<8, 12, 8, 1, PFB_FMT_CF32, 8, 2, 2, 4, 1, 4, 3, 0, 12, false, 4>;  // cfg1's own shape and format
+using Cfg16x12i8 = FastCfg<16, 12, 16, 1, PFB_FMT_INT8_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, true, 4>;
+using Cfg8x12i8 = FastCfg<8, 12, 8, 1, PFB_FMT_INT8_IQ, 8, 2, 2, 4, 1, 4, 3, 0, 12, true, 4>;
+using Cfg8x12f32 = FastCfg<8, 12, 8, 1, PFB_FMT_CF32, 8, 2, 2, 4, 1, 4, 3, 0, 12, true, 4>;
 
 static const FastEntry kRows[] = {
     entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 512, 0),
     entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 32, 0),
     entry<Cfg256x8i16>("pfb_fast<M256,P8,D256,int16>", 32, 0),
     entry<Cfg32x12i16>("pfb_fast<M32,P12,D32,int16>", 512, 0),
-    entry<Cfg16x12i16>("pfb_fast<M16,P12,D16,int16>", 512, 0),
-    entry<Cfg8x12i16>("pfb_fast<M8,P12,D8,int16>", 512, 0),
+    seg_entry<Cfg16x12i16>("pfb_fast<M16,P12,D16,int16>", 1024),
+    seg_entry<Cfg8x12i16>("pfb_fast<M8,P12,D8,int16>", 1024),
     entry<Cfg32x12i8>("pfb_fast<M32,P12,D32,int8>", 512, 0),
-    entry<Cfg16x12i8>("pfb_fast<M16,P12,D16,int8>", 512, 0),
-    entry<Cfg8x12i8>("pfb_fast<M8,P12,D8,int8>", 512, 0),
-    entry<Cfg8x12f32>("pfb_fast<M8,P12,D8,cf32>", 512, 0),
+    seg_entry<Cfg16x12i8>("pfb_fast<M16,P12,D16,int8>", 1024),
+    seg_entry<Cfg8x12i8>("pfb_fast<M8,P12,D8,int8>", 1024),
+    seg_entry<Cfg8x12f32>("pfb_fast<M8,P12,D8,cf32>", 1024),
     entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 7),
     entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 7),
 };

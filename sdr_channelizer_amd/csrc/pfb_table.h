@@ -15,6 +15,14 @@ constexpr FastEntry entry(const char* name, int default_fpb, int default_schedul
                                   default_fpb, K::CPT, default_schedule, kChannelMajorOk<K>}};
 }
 
+// small banks: SegKernel, 64 / M segments of the run per wave; frames_per_block is a multiple of C * SEG
+template <class K>
+constexpr FastEntry seg_entry(const char* name, int default_fpb) {
+  return FastEntry{K::M, K::P, K::D, K::FMT,
+                   FastKernelInfo{&launch_seg<K>, &init_tables<K>, K::TAPS_LANE_FLOATS, K::TW_LANE_ELEMS, name,
+                                  SegKernel<K>::CT, default_fpb, 1, 0, true}};
+}
+
 struct FastTablePart { const FastEntry* rows; int count; };
 FastTablePart fast_table_m64();
 FastTablePart fast_table_mid();
