@@ -1281,7 +1281,7 @@ struct FastKernel {
 };
 
 // ---------------------------------------------------------------------------------
-// Small banks (M = 8, 16, 32: numBands = fs * 1e-6 at 8 ... 32 Msps).  With one column per lane only M of the
+// Small banks (M = 8, 10, 16, 20, 40, ...: numBands = fs * 1e-6 at 8 ... 40 Msps).  With one column per lane only M of the
 // wave's 64 lanes would filter.  Here the workgroup's run of frames is cut into SEG = 64 / M contiguous
 // segments and lane (seg, col) slides column col's window over segment seg: all 64 lanes filter, a chunk is
 // C * SEG frames, and the two FFT passes run over all of them (ping-pong LDS buffers, twiddles from the table).
@@ -1291,8 +1291,8 @@ struct SegKernel {
   using ST = SampleT<K::FMT>;
   using raw_t = typename ST::raw_t;
   static constexpr int M = K::M, P = K::P, D = K::D, C = K::C, W = K::W;
-  static constexpr int SEG = 64 / M, CT = C * SEG, NW = W - 1 + C;
-  static_assert(K::NT == 64 && K::CPT == 1 && K::OS == 1 && K::NP == 2 && K::PINGPONG && 64 % M == 0 && SEG >= 2, "small banks");
+  static constexpr int SEG = 64 / M, CT = C * SEG, NW = W - 1 + C;  // M * SEG lanes work, the rest (M not dividing 64) idle
+  static_assert(K::NT == 64 && K::CPT == 1 && K::OS == 1 && K::NP == 2 && K::PINGPONG && SEG >= 1, "small banks");
 
   PFB_DEV v2f cvt(raw_t r) {
     float re, im;
@@ -1364,7 +1364,9 @@ struct SegKernel {
 
   template <bool INTERIOR>
   PFB_DEV void run_impl(const KernelParams& p, float2* lds, long long f_begin, long long l_seg) {
-    const int tid = threadIdx.x, seg = tid / M, col = tid % M;
+    const int tid = threadIdx.x;
+    const bool lane_on = (64 % M == 0) || tid < SEG * M;
+    const int seg = lane_on ? tid / M : 0, col = lane_on ? tid % M : 0;  // idle lanes shadow lane 0 and never write
     const long long f_seg = f_begin + seg * l_seg;                  // my segment's first frame
     const long long s_row0 = (f_seg - (W - 1)) * D + p.base + col;  // my column in the first halo row
     // taps of my column, two per register pair (the same table FastKernel::setup reads)
@@ -1407,8 +1409,10 @@ struct SegKernel {
           if (q & 1) fma_tap_hi(acc[t], x[W - 1 + t - q], hp[q >> 1]);
           else fma_tap_lo(acc[t], x[W - 1 + t - q], hp[q >> 1]);
         }
+      if (lane_on) {
 #pragma unroll
-      for (int t = 0; t < C; ++t) reinterpret_cast<v2f*>(buf0)[(seg * C + t) * K::FS + upos] = acc[t] * conj_mul;
+        for (int t = 0; t < C; ++t) reinterpret_cast<v2f*>(buf0)[(seg * C + t) * K::FS + upos] = acc[t] * conj_mul;
+      }
       team_sync<true>();
       pass<0>(p, buf0, buf1, tid, f_begin, l_seg, c0);
       team_sync<true>();

@@ -29,6 +29,11 @@ using Cfg32x12i8 = FastCfg<32, 12, 32, 1, PFB_FMT_INT8_IQ, 8, 2, 8, 4, 1, 4, 9, 
 using Cfg16x12i8 = FastCfg<16, 12, 16, 1, PFB_FMT_INT8_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, true, 4>;
 using Cfg8x12i8 = FastCfg<8, 12, 8, 1, PFB_FMT_INT8_IQ, 8, 2, 2, 4, 1, 4, 3, 0, 12, true, 4>;
 using Cfg8x12f32 = FastCfg<8, 12, 8, 1, PFB_FMT_CF32, 8, 2, 2, 4, 1, 4, 3, 0, 12, true, 4>;
+// numBands at the bladeRF's round rates 10 / 20 / 40 Msps: 2 x 5, 4 x 5, 8 x 5 (5-point DFT); 6, 3 and 1 segments per
+// wave (60 / 60 / 40 of 64 lanes work); 2-way LDS conflicts on some accesses
+using Cfg10x12i16 = FastCfg<10, 12, 10, 1, PFB_FMT_INT16_IQ, 8, 2, 2, 5, 1, 5, 2, 0, 10, true, 4>;
+using Cfg20x12i16 = FastCfg<20, 12, 20, 1, PFB_FMT_INT16_IQ, 8, 2, 4, 5, 1, 5, 5, 0, 28, true, 4>;
+using Cfg40x12i16 = FastCfg<40, 12, 40, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 5, 1, 5, 9, 0, 45, true, 4>;
 
 static const FastEntry kRows[] = {
     entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 512, 0),
@@ -41,6 +46,9 @@ static const FastEntry kRows[] = {
     seg_entry<Cfg16x12i8>("pfb_fast<M16,P12,D16,int8>", 1024),
     seg_entry<Cfg8x12i8>("pfb_fast<M8,P12,D8,int8>", 1024),
     seg_entry<Cfg8x12f32>("pfb_fast<M8,P12,D8,cf32>", 1024),
+    seg_entry<Cfg10x12i16>("pfb_fast<M10,P12,D10,int16>", 1008),
+    seg_entry<Cfg20x12i16>("pfb_fast<M20,P12,D20,int16>", 1008),
+    seg_entry<Cfg40x12i16>("pfb_fast<M40,P12,D40,int16>", 1024),
     entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 7),
     entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 7),
 };

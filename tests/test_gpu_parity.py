@@ -59,7 +59,8 @@ def test_cfg2_uses_the_fast_kernel(golden_dir):
                                           (128, 12, 64, "int16", 12), (1024, 16, 1024, "int16", 16),
                                           (56, 12, 56, "int16", 12), (8, 12, 8, "int16", 12),
                                           (560, 12, 560, "int16", 12), (560, 12, 560, "int8", 8), (56, 12, 56, "int8", 8),
-                                          (32, 12, 32, "int16", 12), (16, 12, 16, "int16", 12)])
+                                          (32, 12, 32, "int16", 12), (16, 12, 16, "int16", 12), (20, 12, 20, "int16", 12),
+                                          (10, 12, 10, "int16", 12), (40, 12, 40, "int16", 12)])
 @pytest.mark.parametrize("q0", [0, 3])
 def test_one_hot_tap_bit_exact(M, P, D, fmt, bw, q0):
     """h = delta[n - M q0] => every channel of frame m equals x[mD + D-1 - M q0] exactly:
@@ -84,7 +85,8 @@ def test_one_hot_tap_bit_exact(M, P, D, fmt, bw, q0):
     (256, 8, 256, "int8", 8, 1 << 17), (128, 12, 64, "int16", 12, 1 << 16), (1024, 16, 1024, "int16", 16, 1 << 18),
     (32, 12, 32, "int16", 12, 1 << 14), (16, 4, 8, "int16", 16, 1 << 12), (56, 12, 56, "int16", 12, 56 * 300),
     (12, 5, 4, "int8", 8, 4 * 500), (560, 12, 560, "int16", 12, 560 * 150 + 31), (560, 12, 560, "int8", 8, 560 * 64),
-    (56, 12, 56, "int8", 8, 56 * 1500 + 3), (16, 12, 16, "int16", 12, 16 * 4000 + 9), (8, 12, 8, "int16", 12, 8 * 9000 + 3)])
+    (56, 12, 56, "int8", 8, 56 * 1500 + 3), (16, 12, 16, "int16", 12, 16 * 4000 + 9), (8, 12, 8, "int16", 12, 8 * 9000 + 3),
+    (20, 12, 20, "int16", 12, 20 * 3000 + 7), (10, 12, 10, "int16", 12, 10 * 5000 + 3), (40, 12, 40, "int16", 12, 40 * 2100 + 11)])
 def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     rng = np.random.default_rng(n + M)
     if fmt == "cf32":
@@ -98,7 +100,8 @@ def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     assert rel(y, want) < REL_TOL
 
 
-@pytest.mark.parametrize("M,P,D", [(64, 12, 64), (128, 12, 64), (56, 12, 56), (560, 12, 560), (32, 12, 32), (8, 12, 8)])
+@pytest.mark.parametrize("M,P,D", [(64, 12, 64), (128, 12, 64), (56, 12, 56), (560, 12, 560), (32, 12, 32), (8, 12, 8),
+                                   (20, 12, 20), (10, 12, 10)])
 @pytest.mark.parametrize("kw", [dict(fftshift=True), dict(conjugate_input=True), dict(derotate=True),
                                 dict(input_offset=0), dict(input_offset=5),
                                 dict(fftshift=True, conjugate_input=True, derotate=True)])
@@ -116,7 +119,8 @@ def test_switches(oracle, M, P, D, kw):
 
 @pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (16, 4, 8, "int16", 12), (256, 8, 256, "int8", 8),
                                           (1024, 16, 1024, "int16", 16), (128, 12, 64, "int16", 12),
-                                          (56, 12, 56, "int16", 12), (560, 12, 560, "int16", 12)])
+                                          (56, 12, 56, "int16", 12), (560, 12, 560, "int16", 12), (8, 12, 8, "int16", 12),
+                                          (20, 12, 20, "int16", 12)])
 def test_channel_major_layout(oracle, M, P, D, fmt, bw):
     """PFB_LAYOUT_CHANNEL_MAJOR = MATLAB's column-major F x M.  Every fused shape has a channel-major
     instantiation of its sliding-run kernel; (16, 4, 8) has no fused path and takes the generic kernel."""
@@ -154,7 +158,8 @@ def test_channel_major_device_path_is_bit_identical_to_frame_major():
 
 
 @pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (128, 12, 64, "int16", 12), (56, 12, 56, "int16", 12),
-                                          (256, 8, 256, "int8", 8), (560, 12, 560, "int16", 12), (16, 12, 16, "int16", 12)])
+                                          (256, 8, 256, "int8", 8), (560, 12, 560, "int16", 12), (16, 12, 16, "int16", 12),
+                                          (20, 12, 20, "int16", 12), (40, 12, 40, "int16", 12)])
 def test_chunked_equals_one_shot_bit_exact(M, P, D, fmt, bw):
     """The handle is stateful like the System object (channelizer_example.m:50-56): any split of
     the stream -- including pieces that are not multiples of D -- gives identical bits."""
