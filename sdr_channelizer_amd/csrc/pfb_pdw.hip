@@ -225,6 +225,18 @@ __global__ void __launch_bounds__(256) pdw_hist_kernel(const float2* y, long lon
   }
 }
 
+// rank[0..M) = lo, rank[M..2M) = hi: the two sample ranks of the bracket (no host buffer, no sync)
+__global__ void pdw_fill_ranks_kernel(unsigned long long* rank, int M, unsigned long long lo, unsigned long long hi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * M) rank[i] = i < M ? lo : hi;
+}
+
+// thr = noise floor * 10^(SNR/10) on the device, so the edge stage can be queued before the host has seen the medians
+__global__ void pdw_thr_kernel(const double* nf, double gain, double* thr, int M) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) thr[i] = nf[i] * gain;
+}
+
 // choose the digit holding rank[col]; one thread per column
 __global__ void pdw_pick_kernel(int M, int pass, unsigned* hist, unsigned long long* prefix,
                                 unsigned long long* rank, unsigned* bucket, unsigned long long* below) {
@@ -508,8 +520,11 @@ __device__ __forceinline__ void word_scan(unsigned long long f0, unsigned long l
 
 // comparison masks of the F x M matrix, laid out [word][channel].  grid = (column groups, word groups of
 // 4): one word (64 frames) per wave, lane = channel.  Frames past F are the identity (f0 = 0, f1 = 1).
+// only_if != nullptr: run only when *only_if has bit 4 or 8 set (the bracket pass's provisional masks are unusable)
 __global__ void __launch_bounds__(256) pdw_mask_kernel(const float2* y, long long F, int M, const double* thr,
-                                                       unsigned long long* f0, unsigned long long* f1, long long words) {
+                                                       unsigned long long* f0, unsigned long long* f1, long long words,
+                                                       const unsigned* only_if) {
+  if (only_if && (*only_if & 12u) == 0u) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
   const long long w = (long long)blockIdx.y * 4 + wave;
@@ -1100,9 +1115,14 @@ EdgeStage take_edge_stage(Arena& ws, long long words, long long ntiles, uint32_t
 
 // masks (e.f0, e.f1) and noise floors (e.nf) are on the device: tile summaries, scan, edge lists, one
 // workgroup per pulse, PDWs back to the host.
+// d_check / h_check / h_nf (optional): flags of an optimistic noise-floor pass and its medians, fetched with the edge
+// totals in the one sync; if the flags say the medians are not valid (bits 1 | 2) the function stops there and
+// returns kRedo so that the caller can take the slow path and call again.
+constexpr int kRedo = 1;
 template <class Src>
 int edges_and_pulses(Src src, int Mi, long long ntiles, int tile_words, const EdgeStage& e, Arena& ws2, double fs, double fc, double t0,
-                     unsigned flags, pfb_pdw* out, uint64_t capacity, uint64_t* count, hipStream_t st) {
+                     unsigned flags, pfb_pdw* out, uint64_t capacity, uint64_t* count, hipStream_t st,
+                     const unsigned* d_check = nullptr, unsigned* h_check = nullptr, double* h_nf = nullptr) {
   int rc = PFB_OK;
   const uint32_t M = (uint32_t)Mi;
   const size_t tm = (size_t)ntiles * M;
@@ -1120,7 +1140,12 @@ int edges_and_pulses(Src src, int Mi, long long ntiles, int tile_words, const Ed
   }
   PDW_TRY(hipGetLastError());
   PDW_TRY(hipMemcpyAsync(h_tot.data(), e.tot, 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  if (d_check) {
+    PDW_TRY(hipMemcpyAsync(h_check, d_check, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    PDW_TRY(hipMemcpyAsync(h_nf, e.nf, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
   PDW_TRY(hipStreamSynchronize(st));
+  if (d_check && (*h_check & 3u)) return kRedo;
   for (uint32_t b = 0; b < M; ++b) {  // channels outermost, like the reference's for bin = 1:M
     h_base[b] = total_s; h_base[M + b] = total_e;
     total_s += h_tot[b]; total_e += h_tot[M + b];
@@ -1226,9 +1251,8 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
   EdgeStage e{};
   std::vector<unsigned> h_bucket(M);
   std::vector<unsigned long long> h_rank(M);
-  std::vector<double> h_nf(M), h_thr(M), h_binf(M);
+  std::vector<double> h_nf(M), h_binf(M);
   unsigned h_flags = 0;
-  bool have_nf = false, masks_ready = false;
   int passes = 0;
   const double gain = std::pow(10.0, snr_threshold_db / 10.0);  // :74-75 (dB applied to magnitude with /10)
   const int row_blocks = (int)std::min<long long>(1024, std::max<long long>(1, F / 256));
@@ -1266,18 +1290,20 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
   e = take_edge_stage(ws, words, ntiles, M, true);
 
   PDW_TRY(hipMemsetAsync(d_hist, 0, 2 * (size_t)M * 256 * sizeof(unsigned), st));
+  pfb_center_frequencies(M, fs_in, h_binf.data());  // :42, before fs is decimated
+  PDW_TRY(hipMemcpyAsync(e.binf, h_binf.data(), M * sizeof(double), hipMemcpyHostToDevice, st));
 
-  // ---- noise floor (:73), sampled bracket first
+  // ---- noise floor (:73), sampled bracket first.  Everything up to the edge totals is queued without a host sync:
+  // sample selects, the bracket pass (which also leaves provisional masks), the candidate select, thresholds on the
+  // device, the patch of the unclassified samples (or a full mask pass if the device finds the provisional masks
+  // unusable), tile summaries and scan.  The host reads flags, medians and totals in one go.
   if (sampled) {
     const int sblocks = (int)std::min<long long>(1024, std::max<long long>(1, ns / 1024));  // few, long blocks: the 64 KB LDS histogram's clear and flush dominate a short one
-    // radix select of the two bracket ranks on the sample, both in the same launches (select 0 = low, 1 = high)
-    std::vector<unsigned long long> h_rank2(2 * (size_t)M);
-    std::fill(h_rank2.begin(), h_rank2.begin() + M, (unsigned long long)std::max<long long>(0, ns / 2 - delta));
-    std::fill(h_rank2.begin() + M, h_rank2.end(), (unsigned long long)std::min<long long>(ns - 1, ns / 2 + delta));
     PDW_TRY(hipMemsetAsync(d_prefix, 0, 2 * (size_t)M * sizeof(unsigned long long), st));
-    PDW_TRY(hipMemcpyAsync(d_rank, h_rank2.data(), 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
-    PDW_TRY(hipStreamSynchronize(st));  // h_rank2 goes out of scope
-    for (int ps = 0; ps < kSamplePasses; ++ps) {
+    hipLaunchKernelGGL(pdw_fill_ranks_kernel, dim3((2 * Mi + 255) / 256), dim3(256), 0, st, d_rank, Mi,
+                       (unsigned long long)std::max<long long>(0, ns / 2 - delta),
+                       (unsigned long long)std::min<long long>(ns - 1, ns / 2 + delta));
+    for (int ps = 0; ps < kSamplePasses; ++ps) {  // both bracket ranks in the same launches (select 0 = low, 1 = high)
       hipLaunchKernelGGL(pdw_hist_kernel, dim3(cgroups, sblocks, 2), dim3(256), 0, st, d_y, ns, stride, Mi, ps,
                          (const unsigned long long*)d_prefix, d_hist);
       hipLaunchKernelGGL(pdw_pick_kernel, dim3((2 * Mi + 63) / 64), dim3(64), 0, st, 2 * Mi, ps, d_hist, d_prefix, d_rank,
@@ -1294,16 +1320,23 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
     hipLaunchKernelGGL(pdw_bracket_finish_kernel, dim3(Mi), dim3(1024), 0, st, F, (const double*)d_cand, cap,
                        (const unsigned*)d_cand_n, (const unsigned long long*)d_below, (const unsigned long long*)d_maxbelow,
                        (const unsigned long long*)d_prefix, (const unsigned long long*)d_prefix_hi, gain, e.nf, d_flags);
+    hipLaunchKernelGGL(pdw_thr_kernel, dim3((Mi + 255) / 256), dim3(256), 0, st, (const double*)e.nf, gain, d_thr, Mi);
+    hipLaunchKernelGGL(pdw_patch_kernel, dim3(64), dim3(256), 0, st, d_y, Mi, (const double*)d_thr,
+                       (const unsigned long long*)d_und, (const unsigned*)d_und_n, e.f0, e.f1);
+    hipLaunchKernelGGL(pdw_mask_kernel, dim3(cgroups, (unsigned)((words + 3) / 4)), dim3(256), 0, st, d_y, F, Mi,
+                       (const double*)d_thr, e.f0, e.f1, words, (const unsigned*)d_flags);
     PDW_TRY(hipGetLastError());
-    PDW_TRY(hipMemcpyAsync(&h_flags, d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    PDW_TRY(hipMemcpyAsync(h_nf.data(), e.nf, M * sizeof(double), hipMemcpyDeviceToHost, st));
-    PDW_TRY(hipStreamSynchronize(st));
-    masks_ready = (h_flags == 0);          // flags 4 / 8 only spoil the provisional masks, not the medians
-    h_flags &= 3u;
-    have_nf = (h_flags == 0);
+    rc = edges_and_pulses(ChanSrc{d_y, Mi}, Mi, ntiles, tile_words, e, ws2, fs, fc, sample_start_time, flags, out, capacity,
+                          count, st, d_flags, &h_flags, h_nf.data());
+    if (rc != kRedo) {
+      g_pdw_path = h_flags == 0 ? 1 : 4;  // 4: flags 4 / 8 only spoiled the provisional masks, the device redid them
+      if (rc == PFB_OK && noise_floor_out) std::memcpy(noise_floor_out, h_nf.data(), M * sizeof(double));
+      goto done;
+    }
+    rc = PFB_OK;
   }
-  g_pdw_path = have_nf ? (masks_ready ? 1 : 4) : (sampled ? 3 : 2);
-  if (!have_nf) {  // full radix select of rank F/2, then the exact finish
+  g_pdw_path = sampled ? 3 : 2;
+  {  // full radix select of rank F/2, then the exact finish
     std::fill(h_rank.begin(), h_rank.end(), (unsigned long long)(F / 2));
     PDW_TRY(hipMemsetAsync(d_hist, 0, (size_t)M * 256 * sizeof(unsigned), st));
     PDW_TRY(hipMemsetAsync(d_prefix, 0, M * sizeof(unsigned long long), st));
@@ -1325,28 +1358,18 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
                        d_cand_n, d_maxbelow);
     hipLaunchKernelGGL(pdw_median_finish_kernel, dim3(Mi), dim3(256), 0, st, F, passes, d_cand, d_cand_n, d_prefix, d_rank,
                        d_maxbelow, e.nf);
-    PDW_TRY(hipGetLastError());
-    PDW_TRY(hipMemcpyAsync(h_nf.data(), e.nf, M * sizeof(double), hipMemcpyDeviceToHost, st));
-    PDW_TRY(hipStreamSynchronize(st));
-  }
-  {
-    for (uint32_t b = 0; b < M; ++b) h_thr[b] = h_nf[b] * gain;
-    pfb_center_frequencies(M, fs_in, h_binf.data());              // :42, before fs is decimated
-    if (noise_floor_out) std::memcpy(noise_floor_out, h_nf.data(), M * sizeof(double));
-  }
-  PDW_TRY(hipMemcpyAsync(d_thr, h_thr.data(), M * sizeof(double), hipMemcpyHostToDevice, st));
-  PDW_TRY(hipMemcpyAsync(e.binf, h_binf.data(), M * sizeof(double), hipMemcpyHostToDevice, st));
-
-  // ---- edges (:85-135) and pulses (:98-132)
-  if (masks_ready) {  // the bracket pass left the masks; settle the few samples it could not classify
-    hipLaunchKernelGGL(pdw_patch_kernel, dim3(64), dim3(256), 0, st, d_y, Mi, (const double*)d_thr,
-                       (const unsigned long long*)d_und, (const unsigned*)d_und_n, e.f0, e.f1);
-  } else {
+    hipLaunchKernelGGL(pdw_thr_kernel, dim3((Mi + 255) / 256), dim3(256), 0, st, (const double*)e.nf, gain, d_thr, Mi);
     hipLaunchKernelGGL(pdw_mask_kernel, dim3(cgroups, (unsigned)((words + 3) / 4)), dim3(256), 0, st, d_y, F, Mi,
-                       (const double*)d_thr, e.f0, e.f1, words);
+                       (const double*)d_thr, e.f0, e.f1, words, (const unsigned*)nullptr);
+    PDW_TRY(hipGetLastError());
+    if (noise_floor_out) {
+      PDW_TRY(hipMemcpyAsync(h_nf.data(), e.nf, M * sizeof(double), hipMemcpyDeviceToHost, st));
+      PDW_TRY(hipStreamSynchronize(st));
+      std::memcpy(noise_floor_out, h_nf.data(), M * sizeof(double));
+    }
+    rc = edges_and_pulses(ChanSrc{d_y, Mi}, Mi, ntiles, tile_words, e, ws2, fs, fc, sample_start_time, flags, out, capacity,
+                          count, st);
   }
-  PDW_TRY(hipGetLastError());
-  rc = edges_and_pulses(ChanSrc{d_y, Mi}, Mi, ntiles, tile_words, e, ws2, fs, fc, sample_start_time, flags, out, capacity, count, st);
 
 done:
   (void)hipStreamSynchronize(st);
