@@ -21,14 +21,15 @@ using Cfg56x12i16 = FastCfg<56, 12, 56, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 7, 1, 7, 9
 using Cfg56x12i8  = FastCfg<56, 12, 56, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
 // small banks (numBands = fs * 1e-6 at 8 / 16 / 32 Msps, channelizer_example.m:29).  M = 32: the ordinary kernel with
 // half the lanes idle through the FIR (52 %; two segments per wave measured 47 %).  M = 16 and 8: SegKernel, 64 / M
-// segments of the run per wave so that every lane filters (36 -> 49 %, 24 -> 40 %); ping-pong LDS buffers (PP = true)
+// segments of the run per wave so that every lane filters (36 -> 49 %, 24 -> 56 %); ping-pong LDS buffers (PP = true).
+// M = 8 is 4 x 2, not 2 x 4: the last pass then leaves a lane group 4 adjacent channels (32-byte runs), worth 40 -> 56 %
 using Cfg32x12i16 = FastCfg<32, 12, 32, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 4, 1, 4, 9, 0, 36, false, 4>;
 using Cfg16x12i16 = FastCfg<16, 12, 16, 1, PFB_FMT_INT16_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, true, 4>;
-using Cfg8x12i16 = FastCfg<8, 12, 8, 1, PFB_FMT_INT16_IQ, 8, 2, 2, 4, 1, 4, 3, 0, 12, true, 4>;
+using Cfg8x12i16 = FastCfg<8, 12, 8, 1, PFB_FMT_INT16_IQ, 8, 2, 4, 2, 1, 2, 5, 0, 10, true, 4>;
 using Cfg32x12i8 = FastCfg<32, 12, 32, 1, PFB_FMT_INT8_IQ, 8, 2, 8, 4, 1, 4, 9, 0, 36, false, 4>;
 using Cfg16x12i8 = FastCfg<16, 12, 16, 1, PFB_FMT_INT8_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, true, 4>;
-using Cfg8x12i8 = FastCfg<8, 12, 8, 1, PFB_FMT_INT8_IQ, 8, 2, 2, 4, 1, 4, 3, 0, 12, true, 4>;
-using Cfg8x12f32 = FastCfg<8, 12, 8, 1, PFB_FMT_CF32, 8, 2, 2, 4, 1, 4, 3, 0, 12, true, 4>;
+using Cfg8x12i8 = FastCfg<8, 12, 8, 1, PFB_FMT_INT8_IQ, 8, 2, 4, 2, 1, 2, 5, 0, 10, true, 4>;
+using Cfg8x12f32 = FastCfg<8, 12, 8, 1, PFB_FMT_CF32, 8, 2, 4, 2, 1, 2, 5, 0, 10, true, 4>;
 // numBands at the bladeRF's round rates 10 / 20 / 40 Msps: 2 x 5, 4 x 5, 8 x 5 (5-point DFT); 6, 3 and 1 segments per
 // wave (60 / 60 / 40 of 64 lanes work); 2-way LDS conflicts on some accesses
 using Cfg10x12i16 = FastCfg<10, 12, 10, 1, PFB_FMT_INT16_IQ, 8, 2, 2, 5, 1, 5, 2, 0, 10, true, 4>;

@@ -115,7 +115,7 @@ PLANS = {
     "m560_teams": (560, [14, 10, 4], [40, 60, 140], 600, 4, 320),
     "m32": (32, [8, 4], [4, 9], 36, 8, 64),
     "m16": (16, [4, 4], [4, 5], 20, 8, 64),
-    "m8": (8, [2, 4], [4, 3], 12, 8, 64),
+    "m8": (8, [4, 2], [2, 5], 10, 64, 64),
     "m10": (10, [2, 5], [5, 2], 10, 48, 64),
     "m20": (20, [4, 5], [5, 5], 28, 24, 64),
     "m40": (40, [8, 5], [5, 9], 45, 8, 64),
