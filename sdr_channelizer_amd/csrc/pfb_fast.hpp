@@ -276,7 +276,6 @@ struct FastCfg {
   static constexpr int BUF = C * FS;   // one chunk buffer (complex elements)
   static constexpr int LDS_ELEMS = BUF * (PINGPONG ? 2 : 1);
   static_assert(D % CPT == 0, "columns split evenly over threads");
-  static_assert(R(0) % 2 == 0 && (NP < 3 || R(1) % 2 == 0), "non-final radices are even (twiddle rows are float4s)");
   static_assert(M % D == 0 && (M * P) % D == 0, "D divides M");
   static_assert(NP >= 2 && NP <= 3, "2 or 3 passes");
   static_assert(R0_ * R1_ * (NP_ == 3 ? R2_ : 1) == M_, "radices multiply to M");
@@ -293,6 +292,7 @@ struct FastCfg {
 // instantiation, so the extra address arithmetic never costs the frame-major kernels a register.
 template <class K, bool CM = false>
 struct FastKernel {
+  static_assert(K::R(0) % 2 == 0 && (K::NP < 3 || K::R(1) % 2 == 0), "non-final radices are even (twiddle rows are read as float4s)");
   using ST = SampleT<K::FMT>;
   using raw_t = typename ST::raw_t;
   static constexpr int M = K::M, P = K::P, D = K::D, CPT = K::CPT, C = K::C, W = K::W, OS = K::OS, NT = K::NT;
@@ -1331,12 +1331,18 @@ struct SegKernel {
       Dft<R>::run(x);
       if constexpr (!LAST) {
         constexpr int S1 = K::S(I + 1), RS1 = K::RS(I + 1);
-        const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(I) + rest * R);
+        if constexpr (R % 2 == 0) {
+          const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(I) + rest * R);
 #pragma unroll
-        for (int k2 = 0; k2 < R / 2; ++k2) {
-          const float4 t = t4[k2];
-          if (k2 > 0) x[2 * k2] = cmul_w(x[2 * k2], (v2f){t.x, t.y});
-          x[2 * k2 + 1] = cmul_w(x[2 * k2 + 1], (v2f){t.z, t.w});
+          for (int k2 = 0; k2 < R / 2; ++k2) {
+            const float4 t = t4[k2];
+            if (k2 > 0) x[2 * k2] = cmul_w(x[2 * k2], (v2f){t.x, t.y});
+            x[2 * k2 + 1] = cmul_w(x[2 * k2 + 1], (v2f){t.z, t.w});
+          }
+        } else {  // odd radix: the table rows are not 16-byte aligned, read them element by element
+          const float2* t2 = p.tw_lane + K::TW_OFF(I) + rest * R;
+#pragma unroll
+          for (int k = 1; k < R; ++k) x[k] = cmul_w(x[k], (v2f){t2[k].x, t2[k].y});
         }
         if (active) {
           const int n1 = rest / S1, rest2 = rest % S1;

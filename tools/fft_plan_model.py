@@ -116,7 +116,7 @@ PLANS = {
     "m32": (32, [8, 4], [4, 9], 36, 8, 64),
     "m16": (16, [4, 4], [4, 5], 20, 8, 64),
     "m8": (8, [4, 2], [2, 5], 10, 64, 64),
-    "m10": (10, [2, 5], [5, 2], 10, 48, 64),
+    "m10": (10, [5, 2], [2, 5], 10, 48, 64),
     "m20": (20, [10, 2], [2, 15], 42, 24, 64),
     "m40": (40, [8, 5], [5, 9], 45, 8, 64),
 }
