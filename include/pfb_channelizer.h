@@ -94,7 +94,9 @@ enum {
 typedef struct pfb_config {
   uint32_t struct_size;        /* = sizeof(pfb_config), for ABI growth               */
   uint32_t num_channels;       /* M  (reference: fs*1e-6, channelizer_example.m:29)  */
-  uint32_t taps_per_channel;   /* P  (dsp.Channelizer default 12)                    */
+  uint32_t taps_per_channel;   /* P  (dsp.Channelizer default 12).  Fewer taps than a    */
+                               /* fused shape has run on that shape with zeros appended  */
+                               /* (pfb_history_samples reports the padded length)        */
   uint32_t decimation;         /* D: 0 or M = maximally decimated, M/2 = 2x oversampled */
   const float* taps;           /* M*P prototype taps h[n], copied at create          */
   uint32_t sample_format;      /* pfb_sample_format                                  */

@@ -367,10 +367,19 @@ int pfb_create(const pfb_config* cfg, pfb_handle** out) {
   if (!cfg || !out) return PFB_ERR_BAD_ARG;
   *out = nullptr;
   if (cfg->struct_size != sizeof(pfb_config) || !cfg->taps) return PFB_ERR_BAD_ARG;
-  const uint32_t M = cfg->num_channels, P = cfg->taps_per_channel;
+  const uint32_t M = cfg->num_channels, P_given = cfg->taps_per_channel;
   const uint32_t D = cfg->decimation ? cfg->decimation : M;
-  if (M < 2 || P < 1 || D < 1 || D > M) return PFB_ERR_BAD_ARG;
-  if (M > 4096 || P > 64) return PFB_ERR_UNSUPPORTED;
+  if (M < 2 || P_given < 1 || D < 1 || D > M) return PFB_ERR_BAD_ARG;
+  if (M > 4096 || P_given > 64) return PFB_ERR_UNSUPPORTED;
+  // A prototype with fewer taps per channel than a fused shape has is the same filter with zero taps appended
+  // (h[n] = 0 for n >= M * P adds exact zeros to every branch sum), so it runs on that shape's kernel -- which is
+  // memory-bound anyway -- instead of falling to the generic one.  From here on the handle simply has P taps per
+  // channel (history, state blob and halo sizes follow).
+  uint32_t P = P_given;
+  if (cfg->sample_format <= PFB_FMT_CF32 && !pfb::find_fast_kernel((int)M, (int)P, (int)D, (int)cfg->sample_format)) {
+    for (uint32_t p2 = P_given + 1; p2 <= 16; ++p2)
+      if (pfb::find_fast_kernel((int)M, (int)p2, (int)D, (int)cfg->sample_format)) { P = p2; break; }
+  }
   if (cfg->sample_format > PFB_FMT_CF32) return PFB_ERR_BAD_FORMAT;
   if (cfg->output_layout > PFB_LAYOUT_CHANNEL_MAJOR) return PFB_ERR_BAD_ARG;
   int bw = (int)cfg->bit_width;
@@ -403,10 +412,10 @@ int pfb_create(const pfb_config* cfg, pfb_handle** out) {
   h->fast = pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt, 0, h->layout == PFB_LAYOUT_CHANNEL_MAJOR);
 
   DeviceGuard g(dev);
-  const size_t L = (size_t)M * P;
-  std::vector<float> taps(L);
+  const size_t L = (size_t)M * P, L_given = (size_t)M * P_given;
+  std::vector<float> taps(L, 0.0f);
   const float scale = std::ldexp(1.0f, -(bw - 1));  // power of two: h*scale is exact
-  for (size_t i = 0; i < L; ++i) taps[i] = cfg->taps[i] * scale;
+  for (size_t i = 0; i < L_given; ++i) taps[i] = cfg->taps[i] * scale;
   std::vector<float2> tw(M);
   const double two_pi = 6.283185307179586476925286766559;
   for (uint32_t m = 0; m < M; ++m) {

@@ -250,6 +250,28 @@ def test_every_registered_plan_variant_matches_the_oracle(oracle, M, P, nvar):
     assert len(names) == nvar
 
 
+@pytest.mark.parametrize("M,P,D,fmt,bw,P_fused", [(64, 8, 64, "int16", 12, 12), (64, 5, 64, "int8", 8, 12), (256, 6, 256, "int8", 8, 8),
+                                                  (1024, 10, 1024, "int16", 16, 16), (128, 7, 64, "int16", 12, 12),
+                                                  (8, 3, 8, "int16", 12, 12)])
+def test_shorter_prototypes_run_on_the_fused_shapes(oracle, M, P, D, fmt, bw, P_fused):
+    """taps_per_channel below a fused shape's: the same filter with zero taps appended, so the fused kernel serves it
+    (the oracle is evaluated with the ORIGINAL P); the stream state grows to the padded length."""
+    n = D * 900 + 13
+    iq = synth.pulsed_iq_numpy(n, bw, np.int8 if fmt == "int8" else np.int16, seed=M + P)
+    h = np.random.default_rng(P).standard_normal(M * P).astype(np.float32) / M
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw) as ch:
+        y = ch(iq)
+        assert ch.last_kernel.startswith("pfb_fast<M%d,P%d," % (M, P_fused))
+        assert ch.history_samples == M * P_fused + D
+        ch.reset()
+        cut = D * 333 + 5
+        assert np.array_equal(np.concatenate([ch(iq[:cut]), ch(iq[cut:])]), y)
+    assert rel(y, oracle_run(oracle, iq, h, M, P, D, bw)) < REL_TOL
+    with Channelizer(M, taps=np.ones(M * 17, np.float32), decimation=D, sample_format=fmt, bit_width=bw) as ch:
+        ch(iq[: D * 40])
+        assert ch.last_kernel == "pfb_generic"      # longer than any fused shape: no padding possible
+
+
 def test_empty_and_tiny_inputs():
     M, P = 64, 12
     h = np.ones(M * P, np.float32)
