@@ -1695,7 +1695,7 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
     }
     if (p.schedule == 4 || p.schedule == 5) {  // FIR / FFT wave pairs: tile_waves = pairs per workgroup, frames_per_block = run length
       const int key = p.tile_waves * 1000 + p.frames_per_block;
-      if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64) {  // tuning sweep set (cfg2 only, keeps build time sane)
+      if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64 && K::P == 12) {  // tuning sweep set (cfg2 only, keeps build time sane)
         switch (key) {
           case 4064: return launch_paired<K, 4, 64, 4>(p, s);
           case 5064: return launch_paired<K, 5, 64, 5>(p, s);   // 10-wave workgroups, 5 waves per SIMD
@@ -1720,7 +1720,7 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       const int key = p.tile_waves * 1000 + p.frames_per_block;
       if (key == 8024) return launch_shared<K, 8, 24>(p, s);
       if (key == 8032) return launch_shared<K, 8, 32>(p, s);
-      if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64) {  // tuning sweep set (cfg2 only, keeps build time sane)
+      if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64 && K::P == 12) {  // tuning sweep set (cfg2 only, keeps build time sane)
         switch (key) {
           case 4032: return launch_shared<K, 4, 32>(p, s);
           case 8048: return launch_shared<K, 8, 48>(p, s);
@@ -1731,7 +1731,7 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       return launch_shared<K, 8, 24>(p, s);  // any other shape: the tuned default
     }
   }
-  if constexpr (K::NT == 64 && K::M == 64 && K::FMT == PFB_FMT_INT16_IQ && K::C == 8) {  // access-shape study schedules (cfg2 only)
+  if constexpr (K::NT == 64 && K::M == 64 && K::FMT == PFB_FMT_INT16_IQ && K::C == 8 && K::P == 12) {  // access-shape study schedules (cfg2 only)
     if (p.schedule == 2) {  // one chunk per wave, tile_waves adjacent chunks per workgroup
       if (p.tile_waves == 1) return launch_tile<K, 1>(p, s);
       return launch_tile<K, 8>(p, s);

@@ -193,11 +193,14 @@ hipError_t launch_stream_copy(const void* in, void* out, long long n_vec16, hipS
 using Cfg64x12i16 = FastCfg<64, 12, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
 using Cfg64x12i8  = FastCfg<64, 12, 64, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
 using Cfg64x12f32 = FastCfg<64, 12, 64, 1, PFB_FMT_CF32,     8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
+// 13 ... 16 taps per band on the cfg2 bank (shorter prototypes are zero-padded onto the 12-tap kernels at create)
+using Cfg64x16i16 = FastCfg<64, 16, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 8, 1, 8, 9, 0, 72, false, 4>;
 
 static const FastEntry kRows[] = {
     entry<Cfg64x12i16>("pfb_fast<M64,P12,D64,int16>", 512, 4),
     entry<Cfg64x12i8>("pfb_fast<M64,P12,D64,int8>", 256, 7),  // 8-bit rows are half as long: pairs over long runs beat the shared-halo tiles by 10 %
     entry<Cfg64x12f32>("pfb_fast<M64,P12,D64,cf32>", 512, 4),
+    entry<Cfg64x16i16>("pfb_fast<M64,P16,D64,int16>", 512, 4),
 };
 
 FastTablePart fast_table_m64() { return FastTablePart{kRows, (int)(sizeof(kRows) / sizeof(kRows[0]))}; }

@@ -252,7 +252,7 @@ def test_every_registered_plan_variant_matches_the_oracle(oracle, M, P, nvar):
 
 @pytest.mark.parametrize("M,P,D,fmt,bw,P_fused", [(64, 8, 64, "int16", 12, 12), (64, 5, 64, "int8", 8, 12), (256, 6, 256, "int8", 8, 8),
                                                   (1024, 10, 1024, "int16", 16, 16), (128, 7, 64, "int16", 12, 12),
-                                                  (8, 3, 8, "int16", 12, 12)])
+                                                  (8, 3, 8, "int16", 12, 12), (64, 16, 64, "int16", 12, 16), (64, 14, 64, "int16", 12, 16)])
 def test_shorter_prototypes_run_on_the_fused_shapes(oracle, M, P, D, fmt, bw, P_fused):
     """taps_per_channel below a fused shape's: the same filter with zero taps appended, so the fused kernel serves it
     (the oracle is evaluated with the ORIGINAL P); the stream state grows to the padded length."""
