@@ -85,6 +85,16 @@ def test_product_sources_do_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".c")):
                 text = open(os.path.join(base, f), errors="ignore").read()
                 assert "pfb_oracle" not in text and "pfbo_" not in text and "from oracle" not in text, f
+    # the same goes for the tools and the example; bench.py may use it in its cpu_baseline leg only
+    for sub in ("tools", "examples", "include"):
+        for base, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".cpp", ".hip", ".h")):
+                    text = open(os.path.join(base, f), errors="ignore").read()
+                    assert "pfb_oracle" not in text and "pfbo_" not in text and "from oracle" not in text, f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("from oracle") == 1 and bench.index("from oracle") > bench.index("def cpu_baseline")
+    assert bench.index("from oracle") < bench.index("def main")
 
 
 def test_fft_plan_model_covers_the_registered_plans():
