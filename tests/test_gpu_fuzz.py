@@ -1,0 +1,73 @@
+"""Randomised cross-check of every fused shape against the generic kernel (same library, independent code path:
+branches from global memory, radix-2 or plain DFT): random flags, input offsets, layouts, run lengths, schedules and
+call boundaries.  Seeded, so a failure reproduces."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from sdr_channelizer_amd import Channelizer, synth  # noqa: E402
+from sdr_channelizer_amd import _lib as L  # noqa: E402
+
+# (M, P, D, formats, schedules worth forcing besides the default)
+SHAPES = [
+    (64, 12, 64, ("int16", "int8", "cf32"), (0, 3, 4, 5, 7)),
+    (64, 16, 64, ("int16",), (0, 4, 7)),
+    (128, 12, 64, ("int16",), (0, 3, 7)),
+    (256, 8, 256, ("int8", "int16"), (0,)),
+    (1024, 16, 1024, ("int16",), (0, 6)),
+    (56, 12, 56, ("int16", "int8"), (0, 3, 7)),
+    (560, 12, 560, ("int16", "int8"), (0, 6)),
+    (32, 12, 32, ("int16", "int8"), (0, 7)),
+    (16, 12, 16, ("int16", "int8"), (0,)),
+    (8, 12, 8, ("int16", "int8", "cf32"), (0,)),
+    (10, 12, 10, ("int16",), (0,)),
+    (20, 12, 20, ("int16",), (0,)),
+    (40, 12, 40, ("int16",), (0,)),
+]
+
+
+def make_input(rng, n, fmt):
+    if fmt == "cf32":
+        return (rng.standard_normal((n, 2)) * 0.3).astype(np.float32), 1
+    bw = 8 if fmt == "int8" else int(rng.choice([12, 16]))
+    return synth.pulsed_iq_numpy(n, bw, np.int8 if fmt == "int8" else np.int16, seed=int(rng.integers(1 << 30))), bw
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("PFB_FUZZ_CASES", "48"))))  # more with PFB_FUZZ_CASES=N
+def test_fused_kernels_agree_with_the_generic_kernel(case):
+    rng = np.random.default_rng(1000 + case)
+    M, P, D, fmts, scheds = SHAPES[case % len(SHAPES)]
+    fmt = fmts[int(rng.integers(len(fmts)))]
+    frames = int(rng.integers(40, 2500))
+    n = frames * D + int(rng.integers(0, D))
+    iq, bw = make_input(rng, n, fmt)
+    p_used = P if rng.random() < 0.7 else int(rng.integers(max(1, P - 5), P + 1))   # sometimes a shorter prototype
+    h = (rng.standard_normal(M * p_used) / M).astype(np.float32)
+    kw = dict(fftshift=bool(rng.integers(2)), conjugate_input=bool(rng.integers(2)), derotate=bool(rng.integers(2)),
+              magnitude=bool(rng.integers(2)), channel_major=bool(rng.integers(2)),
+              input_offset=int(rng.integers(-1, D)))
+    cuts = sorted({0, n, *(int(c) for c in rng.integers(0, n, size=int(rng.integers(0, 3))))})
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, **kw) as ch:
+        ch.set_option(L.PFB_OPT_KERNEL, 1)
+        want = ch(iq)
+        assert ch.last_kernel == "pfb_generic"
+        ch.reset()
+        ch.set_option(L.PFB_OPT_KERNEL, 2)
+        if rng.random() < 0.6:
+            ch.set_option(L.PFB_OPT_SCHEDULE, int(scheds[int(rng.integers(len(scheds)))]))
+        if rng.random() < 0.5:
+            ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, int(rng.choice([8, 24, 40, 64, 100, 256, 1000])))
+        if rng.random() < 0.3:
+            ch.set_option(L.PFB_OPT_TILE_WAVES, int(rng.choice([4, 6, 8, 16])))
+        if rng.random() < 0.3:
+            ch.set_option(L.PFB_OPT_XCD_REMAP, int(rng.integers(0, 2)))
+        parts = [ch(iq[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert ch.last_kernel.startswith("pfb_fast")
+        axis = 1 if kw["channel_major"] else 0
+        got = np.concatenate([q for q in parts if q.size], axis=axis) if any(q.size for q in parts) else parts[0]
+    assert got.shape == want.shape, (case, kw)
+    scale = max(float(np.abs(want).max()), 1e-30)
+    assert float(np.abs(got - want).max()) / scale < 3e-6, (case, M, fmt, kw)
