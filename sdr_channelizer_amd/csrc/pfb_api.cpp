@@ -176,8 +176,8 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
       int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
       fpb = ((fpb + c - 1) / c) * c;
       p.schedule = h->opt_schedule >= 0 ? h->opt_schedule : h->fast->default_schedule;
-      if (h->layout == PFB_LAYOUT_CHANNEL_MAJOR)  // channel-major: 0 = sliding runs, 2 = tiles, anything else = the kernel's pick
-        p.schedule = (h->opt_schedule == 0 || h->opt_schedule == 2) ? h->opt_schedule : -1;
+      if (h->layout == PFB_LAYOUT_CHANNEL_MAJOR)  // channel-major: 0 = sliding runs, 2 = tiles, 8 = tiles transposed through LDS, anything else = the kernel's pick
+        p.schedule = (h->opt_schedule == 0 || h->opt_schedule == 2 || h->opt_schedule == 8) ? h->opt_schedule : -1;
       if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
       if (p.schedule == 6 || p.schedule == 7) fpb = ((fpb + 2 * c - 1) / (2 * c)) * (2 * c);  // these kernels walk chunks in pairs
       if (p.schedule == 4 || p.schedule == 5) {
@@ -662,7 +662,7 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_nontemporal = value ? 1 : 0;
       return PFB_OK;
     case PFB_OPT_SCHEDULE:
-      if (value < -1 || value > 7) return PFB_ERR_BAD_ARG;
+      if (value < -1 || value > 8) return PFB_ERR_BAD_ARG;
       h->opt_schedule = (int)value;
       return PFB_OK;
     case PFB_OPT_TILE_WAVES:

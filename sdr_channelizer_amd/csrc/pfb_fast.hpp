@@ -462,6 +462,50 @@ struct FastKernel {
     }
   }
 
+  // The last pass of a single-wave kernel with its outputs left in LDS instead of stored: the chunk's buffer is
+  // overwritten in place by the chunk TRANSPOSED, slot[column * C + frame] (fftshift and the derotation sign
+  // applied), for run_tile_t's channel-major flush.  All of the wave's reads are issued before its first write
+  // (the LDS executes one wave's accesses in order), so no second buffer is needed.
+  PFB_DEV void last_pass_transposed(const KernelParams& p, float2* slot, int tid, long long f0) {
+    constexpr int I = K::NP - 1;
+    constexpr int R = K::R(I), KK = K::K(I), RS = K::RS(I);
+    constexpr int IPF = M / R, ITEMS = C * IPF, ITERS = (ITEMS + NT - 1) / NT;
+    static_assert(NT == 64 && !K::PINGPONG && K::S(I) == 1 && M * C <= K::LDS_ELEMS, "wave-local, in place");
+    v2f x[ITERS][R];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int w = tid + it * NT;
+      const bool active = (ITEMS % NT == 0) || (w < ITEMS);
+      const int fc = w / IPF, item = w % IPF;
+      const v2f* s2 = reinterpret_cast<const v2f*>(slot) + fc * K::FS + item;
+#pragma unroll
+      for (int n = 0; n < R; ++n) x[it][n] = active ? s2[n * RS] : (v2f){0.f, 0.f};
+    }
+    team_sync<true>();
+    const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
+    v2f* t2 = reinterpret_cast<v2f*>(slot);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int w = tid + it * NT;
+      const bool active = (ITEMS % NT == 0) || (w < ITEMS);
+      const int fc = w / IPF, kk = w % IPF;
+      Dft<R>::run(x[it]);
+      if (active) {
+        const bool flip_odd = (OS == 2) && (p.flags & PFB_FLAG_DEROTATE) && ((p.frame0 + f0 + fc) & 1);
+        int col = kk + shift;
+        if (col >= M) col -= M;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          v2f v = x[it][k];
+          if (flip_odd && ((kk + k * KK) & 1)) v = -v;
+          t2[col * C + fc] = v;
+          col += KK;
+          if (col >= M) col -= M;
+        }
+      }
+    }
+  }
+
   // ---- per-thread constants shared by both schedules -------------------------------------------
   struct Consts {
     v2f hp[(W + 1) / 2][CPT];  // taps of this thread's columns, two per register pair
@@ -518,7 +562,7 @@ struct FastKernel {
 
   // FIR of C frames from the window x (x[i] = row f0-(W-1)+i) into LDS, then the FFT passes and the
   // stores.  u_{p_lo + D ph}[t] = sum_q h[ph + OS q] * x[row t - ph - OS q]: one v_pk_fma_f32 per tap.
-  template <bool WAVE_LOCAL = false>
+  template <bool WAVE_LOCAL = false, bool TRANSPOSED = false>
   PFB_DEV void fir_fft_store(const KernelParams& p, const Consts& k, const v2f (&x)[NW][CPT], float2* lds, int tid,
                              long long f0) {
     float2* buf0 = lds;
@@ -548,7 +592,11 @@ struct FastKernel {
     team_sync<WAVE_LOCAL>();
     pass<0>(p, buf0, buf1, tid, f0, k.tw);
     team_sync<WAVE_LOCAL>();
-    if constexpr (K::NP == 2) {
+    if constexpr (TRANSPOSED) {
+      static_assert(K::NP == 2 && WAVE_LOCAL, "single-wave two-pass plans");
+      last_pass_transposed(p, buf1, tid, f0);
+      return;
+    } else if constexpr (K::NP == 2) {
       pass<1>(p, buf1, nullptr, tid, f0, k.tw);
     } else {
       pass<1>(p, buf1, buf0, tid, f0, k.tw);
@@ -1253,6 +1301,100 @@ struct FastKernel {
     fir_fft_store<true>(p, k, x, lds, tid, chunk * C);
   }
 
+  // ---- schedule C', channel-major: short sliding runs whose output is transposed in LDS ----------------------
+  // Channel-major rows are out_ld elements apart, so the last pass's natural store (a few frames of 8 channels
+  // per instruction) scatters 64-byte pieces over 8 DRAM pages -- tools/membench5: 4.6 TB/s write-only, 1.2 TB/s
+  // when out_ld is a power of two.  Here wave w of the workgroup slides over CPW chunks, each chunk ends
+  // transposed in its own LDS slot (last_pass_transposed: no extra buffer), and after one barrier the workgroup
+  // writes the NWV * CPW * C frames of every column as one run: an instruction is 256-512 contiguous bytes of
+  // one or two columns (5.5 TB/s in the same microbenchmark, whatever out_ld is).
+  static constexpr int TSLOT = K::LDS_ELEMS + ((C + 32 - K::LDS_ELEMS % 32) % 32);  // = C (mod 32): slots on distinct banks
+
+  template <bool INTERIOR, int CPW>
+  PFB_DEV void tile_t_impl(const KernelParams& p, float2* slots, int tid, long long f_begin) {
+    const int c0 = tid * CPT;
+    Consts k;
+    setup(p, tid, k);
+    const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
+    v2f x[NW][CPT];
+    raw_t raw[C][CPT];
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) {
+      raw_t t[CPT];
+      load_row<INTERIOR>(p, run_ptr, f_begin - (W - 1) + i, i, c0, t);
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(t[cc]);
+    }
+#pragma unroll
+    for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + t, W - 1 + t, c0, raw[t]);
+#pragma unroll
+    for (int ci = 0; ci < CPW; ++ci) {
+#pragma unroll
+      for (int t = 0; t < C; ++t)
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);
+      if (ci + 1 < CPW) {
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+          const int r = (ci + 1) * C + t;
+          load_row<INTERIOR>(p, run_ptr, f_begin + r, W - 1 + r, c0, raw[t]);
+        }
+      }
+      fir_fft_store<true, true>(p, k, x, slots + ci * TSLOT, tid, f_begin + ci * C);
+      if (ci + 1 < CPW) {
+#pragma unroll
+        for (int i = 0; i < W - 1; ++i)
+#pragma unroll
+          for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
+      }
+    }
+  }
+
+  template <int NWV, int CPW>
+  PFB_DEV void run_tile_t(const KernelParams& p, float2* lds_all) {
+    static_assert(NT == 64 && CM, "one wave per run, channel-major output");
+    constexpr int RL = NWV * CPW * C, NTH = 64 * NWV, IT = (M * RL) / NTH;
+    static_assert((M * RL) % NTH == 0 && (RL & (RL - 1)) == 0 && RL % 32 == 0, "whole flush iterations over 32-frame blocks");
+    const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    long long tile = blockIdx.x;
+    if (p.xcd_remap) {
+      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = tile & 7;
+      tile = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (tile >> 3);
+    }
+    const long long tf0 = tile * RL;
+    if (tf0 >= p.frames) return;  // workgroup-uniform
+    const long long f_begin = tf0 + (long long)wave * (CPW * C);
+    if (f_begin < p.frames) {
+      float2* slots = lds_all + wave * (CPW * TSLOT);
+      const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_begin + CPW * C <= p.frames);
+      if (interior) tile_t_impl<true, CPW>(p, slots, tid, f_begin);
+      else tile_t_impl<false, CPW>(p, slots, tid, f_begin);
+    }
+    team_sync<NWV == 1>();
+    const bool mag = (p.flags & PFB_FLAG_MAGNITUDE) != 0;
+    const v2f* t2 = reinterpret_cast<const v2f*>(lds_all);
+    constexpr int HALF = IT > 8 ? 2 : 1;  // at most 8 values in flight per lane
+#pragma unroll
+    for (int h = 0; h < HALF; ++h) {
+      v2f v[IT / HALF];
+#pragma unroll
+      for (int i = 0; i < IT / HALF; ++i) {
+        const int e = (h * (IT / HALF) + i) * NTH + (int)threadIdx.x, col = e / RL, fr = e % RL;
+        v[i] = t2[(fr / C) * TSLOT + col * C + fr % C];
+      }
+#pragma unroll
+      for (int i = 0; i < IT / HALF; ++i) {
+        const int e = (h * (IT / HALF) + i) * NTH + (int)threadIdx.x, col = e / RL, fr = e % RL;
+        const long long f = tf0 + fr;
+        if (f < p.frames) {
+          const long long idx = (long long)col * p.out_ld + p.out_frame0 + f;
+          if (mag) reinterpret_cast<float*>(p.out)[idx] = sqrtf(v[i].x * v[i].x + v[i].y * v[i].y);
+          else store_c64(p.out + idx, v[i], p.nontemporal);
+        }
+      }
+    }
+  }
+
   PFB_DEV void run_strided(const KernelParams& p, float2* lds) {
     const int tid = threadIdx.x;
     const int c0 = tid * CPT;
@@ -1514,6 +1656,27 @@ hipError_t launch_tile(const KernelParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <class K, int NWV, int CPW>
+__global__ void __launch_bounds__(64 * NWV) pfb_tile_t_kernel(const KernelParams p) {
+  __shared__ float2 lds[NWV * CPW * FastKernel<K, true>::TSLOT];
+  FastKernel<K, true>::template run_tile_t<NWV, CPW>(p, lds);
+}
+
+template <class K, int NWV, int CPW>
+hipError_t launch_tile_t(const KernelParams& p, hipStream_t s) {
+  constexpr int RL = NWV * CPW * K::C;
+  const long long tiles = (p.frames + RL - 1) / RL;
+  hipLaunchKernelGGL((pfb_tile_t_kernel<K, NWV, CPW>), dim3((unsigned)tiles), dim3(64 * NWV), 0, s, p);
+  return hipGetLastError();
+}
+
+// the transposed tile: single-wave two-pass plans whose chunk buffer holds the transposed chunk, rows of whole
+// 32-frame blocks
+template <class K, int NWV, int CPW>
+constexpr bool kTileTOk = K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::M * K::C <= K::LDS_ELEMS &&
+                          (NWV * CPW * K::C) % 32 == 0 && ((NWV * CPW * K::C) & (NWV * CPW * K::C - 1)) == 0 &&
+                          (K::M * NWV * CPW * K::C) % (64 * NWV) == 0;
+
 template <class K, int NWV, int L>
 __global__ void __launch_bounds__(64 * NWV) pfb_shared_kernel(const KernelParams p) {
   using raw_t = typename SampleT<K::FMT>::raw_t;
@@ -1648,6 +1811,24 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
         // one chunk per wave, NWV adjacent chunks per workgroup: the workgroup writes NWV * C consecutive frames of
         // every channel at about the same time, which L2 merges into runs a sliding wave never produces by itself
         // (measured +17 ... +70 % over sliding runs; 16 waves win up to M = 64, 8 above).  schedule -1 = this default.
+        if constexpr (kTileTOk<K, 4, 2>) {  // short runs transposed in LDS: schedule 8, the default where the plan allows
+          if (p.schedule == 8 || p.schedule < 0) {
+            // tile_waves = waves per workgroup, frames_per_block / C = chunks per wave
+            const int key = p.tile_waves * 100 + (p.schedule == 8 ? p.frames_per_block / K::C : 0);
+            switch (key) {
+              case 401: if constexpr (kTileTOk<K, 4, 1>) return launch_tile_t<K, 4, 1>(p, s); break;
+              case 801: if constexpr (kTileTOk<K, 8, 1>) return launch_tile_t<K, 8, 1>(p, s); break;
+              case 202: if constexpr (kTileTOk<K, 2, 2>) return launch_tile_t<K, 2, 2>(p, s); break;
+              case 402: if constexpr (kTileTOk<K, 4, 2>) return launch_tile_t<K, 4, 2>(p, s); break;
+              case 104: if constexpr (kTileTOk<K, 1, 4>) return launch_tile_t<K, 1, 4>(p, s); break;
+              case 204: if constexpr (kTileTOk<K, 2, 4>) return launch_tile_t<K, 2, 4>(p, s); break;
+              default: break;
+            }
+            // measured best: 4 waves x 2 chunks on M = 56, 64, 128; 2 waves x 4 chunks on M = 32
+            if constexpr (K::M <= 32 && kTileTOk<K, 2, 4>) return launch_tile_t<K, 2, 4>(p, s);
+            return launch_tile_t<K, 4, 2>(p, s);
+          }
+        }
         if (p.schedule == 2 || p.schedule < 0) {
           const int nwv = p.schedule < 0 ? (K::M <= 64 ? 16 : 8) : p.tile_waves;
           if constexpr (16 * sizeof(float2) * K::LDS_ELEMS <= 160 * 1024) {
