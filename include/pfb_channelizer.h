@@ -196,11 +196,15 @@ typedef enum pfb_option {
                                 /* with the FIR and the FFT on different waves (M = 64 kernels), */
                                 /* 5 = 4 with resident workgroups walking strided tiles (int16), */
                                 /* 6 = FIR team + FFT team in one workgroup (the M = 1024 plan), */
-                                /* 7 = a FIR wave + an FFT wave per long sliding run             */
+                                /* 7 = a FIR wave + an FFT wave per long sliding run;            */
+                                /* channel-major handles: 0 / 2 as above, 8 = short runs whose   */
+                                /* output is transposed in LDS, 9 = frame-major slabs + a        */
+                                /* transpose kernel (the default of the M = 1024 / 560 plans)    */
   PFB_OPT_GRID = 7,             /* schedules 1/5: workgroups to launch (0 = all that are resident) */
   PFB_OPT_TILE_WAVES = 8,       /* schedules 2/3: waves, 4/5/7: wave pairs per workgroup         */
   PFB_OPT_EXPERIMENT = 9,       /* bit mask of timing experiments; 0 in production               */
-  PFB_OPT_VARIANT = 10          /* n-th fused kernel registered for this shape (0 = default plan) */
+  PFB_OPT_VARIANT = 10,         /* n-th fused kernel registered for this shape (0 = default plan) */
+  PFB_OPT_SLAB_FRAMES = 11      /* channel-major by slabs (schedule 9): frames per slab, 0 = one run per CU */
 } pfb_option;
 int pfb_set_option(pfb_handle* h, int option, int64_t value);
 /* With PFB_OPT_PROFILE on: durations (ms) of the channelizer kernel launches

@@ -27,6 +27,7 @@ PFB_FLAG_FFTSHIFT, PFB_FLAG_CONJUGATE_INPUT, PFB_FLAG_DEROTATE, PFB_FLAG_MAGNITU
 PFB_MEM_HOST, PFB_MEM_DEVICE = 0, 1
 PFB_OPT_KERNEL, PFB_OPT_FRAMES_PER_BLOCK, PFB_OPT_HOST_CHUNK_SAMPLES, PFB_OPT_NONTEMPORAL, PFB_OPT_PROFILE, PFB_OPT_XCD_REMAP = 0, 1, 2, 3, 4, 5
 PFB_OPT_SCHEDULE, PFB_OPT_GRID, PFB_OPT_TILE_WAVES, PFB_OPT_EXPERIMENT, PFB_OPT_VARIANT = 6, 7, 8, 9, 10
+PFB_OPT_SLAB_FRAMES = 11
 
 
 class PfbConfig(C.Structure):

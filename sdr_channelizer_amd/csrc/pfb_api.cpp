@@ -87,6 +87,9 @@ struct pfb_handle {
   int opt_schedule = -1;  // -1: the instantiation's measured default
   int opt_grid = 0;
   int opt_tile_waves = 8;
+  int64_t opt_slab_frames = 0;  // channel-major by slabs: frames per slab (0 = ~32 MiB of output)
+  void* d_slab = nullptr;       // frame-major scratch of the slab path
+  size_t slab_bytes = 0;
   const char* last_kernel = "";
   // host staging: two sets, so chunk i+1 crosses PCIe inbound while chunk i is transformed and chunk i-1 goes out
   void* d_stage_in = nullptr;   // set 0 (also pfb_prime's scratch)
@@ -117,6 +120,7 @@ void free_handle(pfb_handle* h) {
   (void)hipFree(h->d_stage_out);
   (void)hipFree(h->d_stage_in2);
   (void)hipFree(h->d_stage_out2);
+  (void)hipFree(h->d_slab);
   if (h->s_in) (void)hipStreamDestroy(h->s_in);
   if (h->s_out) (void)hipStreamDestroy(h->s_out);
   for (int i = 0; i < 2; ++i) {
@@ -171,13 +175,22 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
       ev = &h->ev_pool[h->ev_used++];
       HIP_TRY(hipEventRecord(ev->first, h->stream));
     }
+    // Channel-major output of a fused shape is written by the kernel itself (its transposed-tile or plain
+    // channel-major instantiation).  The team plans (M = 1024, 560) have none -- their chunks of 4 frames would be
+    // 32-byte runs -- and go by slabs instead: the frame-major kernel fills a scratch slab, a transpose kernel
+    // moves it into place (M = 1024: 2x the 8-wave plan's fused channel-major stores).  A slab must be long enough
+    // to fill the chip with runs, so it does not fit the memory-side cache; PFB_OPT_SCHEDULE 9 forces the slabs on
+    // any shape, PFB_OPT_SLAB_FRAMES sets their length.
+    const bool cm = h->layout == PFB_LAYOUT_CHANNEL_MAJOR;
+    const bool forced_fused = h->opt_schedule == 0 || h->opt_schedule == 2 || h->opt_schedule == 8;
+    const bool by_slabs = cm && want_fast && (!h->fast->channel_major_ok || h->opt_schedule == 9);
     if (want_fast) {
       const int c = h->fast->chunk_frames;
       int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
       fpb = ((fpb + c - 1) / c) * c;
-      p.schedule = h->opt_schedule >= 0 ? h->opt_schedule : h->fast->default_schedule;
-      if (h->layout == PFB_LAYOUT_CHANNEL_MAJOR)  // channel-major: 0 = sliding runs, 2 = tiles, 8 = tiles transposed through LDS, anything else = the kernel's pick
-        p.schedule = (h->opt_schedule == 0 || h->opt_schedule == 2 || h->opt_schedule == 8) ? h->opt_schedule : -1;
+      p.schedule = (h->opt_schedule >= 0 && h->opt_schedule != 9) ? h->opt_schedule : h->fast->default_schedule;
+      if (cm && !by_slabs)  // fused channel-major: 0 = sliding runs, 2 = tiles, 8 = short runs transposed in LDS, else the kernel's pick
+        p.schedule = forced_fused ? h->opt_schedule : -1;
       if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
       if (p.schedule == 6 || p.schedule == 7) fpb = ((fpb + 2 * c - 1) / (2 * c)) * (2 * c);  // these kernels walk chunks in pairs
       if (p.schedule == 4 || p.schedule == 5) {
@@ -190,7 +203,35 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
       const int cpt = h->fast->cols_per_thread;
       const int bmod = ((p.base % cpt) + cpt) % cpt;
       p.vec_ok = (bmod == 0) && (reinterpret_cast<uintptr_t>(d_iq) % (uintptr_t)(h->bps * cpt) == 0);
-      HIP_TRY(h->fast->launch(p, h->stream));
+      if (by_slabs) {
+        long long sf = h->opt_slab_frames > 0 ? h->opt_slab_frames : 256ll * fpb;  // one run per CU
+        sf = std::max<long long>(64, (sf + 63) / 64 * 64);
+        sf = std::max<long long>(sf, (h->hist_samples + h->D - 1) / h->D + 1);  // a later slab's window reaches back into the input, never into the history
+        sf = std::min<long long>(sf, ((long long)frames + 63) / 64 * 64);
+        const size_t need = (size_t)sf * h->M * h->out_elem;
+        if (need > h->slab_bytes) {
+          HIP_TRY(hipStreamSynchronize(h->stream));
+          (void)hipFree(h->d_slab);
+          h->d_slab = nullptr; h->slab_bytes = 0;
+          HIP_TRY(hipMalloc(&h->d_slab, need));
+          h->slab_bytes = need;
+        }
+        for (long long f0 = 0; f0 < (long long)frames; f0 += sf) {
+          pfb::KernelParams q = p;
+          q.layout = PFB_LAYOUT_FRAME_MAJOR;
+          q.out = static_cast<float2*>(h->d_slab);
+          q.frames = std::min<long long>(sf, (long long)frames - f0);
+          q.frame0 = p.frame0 + f0;
+          q.in = static_cast<const char*>(d_iq) + (size_t)f0 * h->D * h->bps;
+          q.n_in = (long long)n - f0 * h->D;
+          if (f0 > 0)  // "history" of a later slab = the input samples in front of it
+            q.hist = static_cast<const char*>(q.in) - (size_t)h->hist_samples * h->bps;
+          HIP_TRY(h->fast->launch(q, h->stream));
+          HIP_TRY(pfb::launch_transpose_slab(h->d_slab, q.frames, h->M, d_out, out_ld, out_frame0 + f0, h->out_elem, h->stream));
+        }
+      } else {
+        HIP_TRY(h->fast->launch(p, h->stream));
+      }
       h->last_kernel = h->fast->name;
     } else {
       HIP_TRY(pfb::launch_generic(p, h->stream));
@@ -409,7 +450,9 @@ int pfb_create(const pfb_config* cfg, pfb_handle** out) {
   h->device = dev;
   h->bps = pfb::bytes_per_sample(h->fmt);
   h->hist_samples = (int)(M * P + D);
-  h->fast = pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt, 0, h->layout == PFB_LAYOUT_CHANNEL_MAJOR);
+  // (a channel-major handle takes the shape's default plan too: plans without a channel-major instantiation of
+  // their own go through frame-major slabs, see enqueue)
+  h->fast = pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt, 0);
 
   DeviceGuard g(dev);
   const size_t L = (size_t)M * P, L_given = (size_t)M * P_given;
@@ -662,7 +705,7 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_nontemporal = value ? 1 : 0;
       return PFB_OK;
     case PFB_OPT_SCHEDULE:
-      if (value < -1 || value > 8) return PFB_ERR_BAD_ARG;
+      if (value < -1 || value > 9) return PFB_ERR_BAD_ARG;
       h->opt_schedule = (int)value;
       return PFB_OK;
     case PFB_OPT_TILE_WAVES:
@@ -680,11 +723,15 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
     case PFB_OPT_EXPERIMENT:
       h->opt_experiment = (int)value;
       return PFB_OK;
+    case PFB_OPT_SLAB_FRAMES:
+      if (value < 0 || value > (1ll << 32)) return PFB_ERR_BAD_ARG;
+      h->opt_slab_frames = value;
+      return PFB_OK;
     case PFB_OPT_VARIANT: {
       if (value < 0 || value > 16) return PFB_ERR_BAD_ARG;
       if ((int)value == h->opt_variant) return PFB_OK;
       const pfb::FastKernelInfo* f =
-          pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt, (int)value, h->layout == PFB_LAYOUT_CHANNEL_MAJOR);
+          pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt, (int)value);
       if (!f) return PFB_ERR_UNSUPPORTED;
       DeviceGuard g(h->device);
       HIP_TRY(hipStreamSynchronize(h->stream));  // the old tables may still be in use

@@ -95,6 +95,8 @@ const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant
 hipError_t launch_generic(const KernelParams& p, hipStream_t s);
 hipError_t launch_update_history(const void* old_hist, const void* in, long long n_in, void* new_hist,
                                  int hist_samples, int bytes_per_sample, hipStream_t s);
+hipError_t launch_transpose_slab(const void* slab, long long frames, int M, void* out, long long out_ld,
+                                 long long out_frame0, int elem_bytes, hipStream_t s);
 hipError_t launch_stream_copy(const void* in, void* out, long long n_vec16, hipStream_t s);
 
 }  // namespace pfb

@@ -32,12 +32,15 @@
 // when; PFB_OPT_SCHEDULE, bit-identical outputs per shape):
 //   0 (A)  one sliding run per workgroup, FIR and FFT by the same threads
 //   1 (B)  persistent workgroups over strided chunks          (access-shape study)
-//   2 (C)  one chunk per wave, adjacent chunks per workgroup  (channel-major default)
+//   2 (C)  one chunk per wave, adjacent chunks per workgroup  (access-shape study; channel-major fallback)
 //   3 (D)  short runs whose halo rows are shared through LDS
 //   4 (F)  D with a FIR wave and an FFT wave per run          (M = 64 default)
 //   5 (G)  F with resident workgroups, halo prefetched HBM -> LDS
 //   6 (T)  a FIR team and an FFT team per workgroup           (M = 1024 / 560 default)
 //   7 (H)  a FIR wave and an FFT wave per long sliding run    (M = 56 default)
+//   8 (C') channel-major only: short sliding runs, each chunk transposed in its LDS buffer, the workgroup's
+//          tile written as 256-512-byte runs per channel       (channel-major default of the single-wave plans)
+//   9      channel-major only, host side (pfb_api.cpp): frame-major slabs + pfb_transpose_slab_kernel
 #pragma once
 
 #include "pfb_common.h"
@@ -1805,12 +1808,9 @@ hipError_t launch_strided(const KernelParams& p, hipStream_t s) {  // persistent
 template <class K>
 hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   if (p.frames <= 0) return hipSuccess;
-  if (p.layout == PFB_LAYOUT_CHANNEL_MAJOR) {  // sliding runs only; the other schedules are frame-major tuning
+  if (p.layout == PFB_LAYOUT_CHANNEL_MAJOR) {  // schedules 8, 2 and 0; the others are frame-major tuning
     if constexpr (kChannelMajorOk<K>) {
       if constexpr (K::NT == 64) {
-        // one chunk per wave, NWV adjacent chunks per workgroup: the workgroup writes NWV * C consecutive frames of
-        // every channel at about the same time, which L2 merges into runs a sliding wave never produces by itself
-        // (measured +17 ... +70 % over sliding runs; 16 waves win up to M = 64, 8 above).  schedule -1 = this default.
         if constexpr (kTileTOk<K, 4, 2>) {  // short runs transposed in LDS: schedule 8, the default where the plan allows
           if (p.schedule == 8 || p.schedule < 0) {
             // tile_waves = waves per workgroup, frames_per_block / C = chunks per wave
@@ -1829,6 +1829,9 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
             return launch_tile_t<K, 4, 2>(p, s);
           }
         }
+        // one chunk per wave, NWV adjacent chunks per workgroup: the workgroup writes NWV * C consecutive frames of
+        // every channel at about the same time, which L2 merges into runs a sliding wave never produces by itself
+        // (measured +17 ... +70 % over sliding runs; 16 waves win up to M = 64, 8 above)
         if (p.schedule == 2 || p.schedule < 0) {
           const int nwv = p.schedule < 0 ? (K::M <= 64 ? 16 : 8) : p.tile_waves;
           if constexpr (16 * sizeof(float2) * K::LDS_ELEMS <= 160 * 1024) {

@@ -171,6 +171,52 @@ hipError_t launch_update_history(const void* old_hist, const void* in, long long
 }
 
 // ---------------------------------------------------------------------------------
+// channel-major by slabs: slab[frames][M] (frame-major, written a moment ago by a channelizer kernel)
+// -> out[col * out_ld + out_frame0 + f].  64 x 64 tiles through LDS: rows are read 64 columns at
+// a time (512 contiguous bytes per wave instruction) and columns written 64 frames at a time (512 contiguous bytes).
+
+template <typename T>
+__global__ void __launch_bounds__(256) pfb_transpose_slab_kernel(const T* slab, long long frames, int M, T* out,
+                                                                 long long out_ld, long long out_frame0) {
+  __shared__ T tile[64][65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 64;
+  const long long f0 = (long long)blockIdx.y * 64;
+  T v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const long long f = f0 + wave * 16 + i;
+    v[i] = (f < frames && c0 + lane < M) ? slab[f * M + c0 + lane] : T{};
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tile[lane][wave * 16 + i] = v[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = tile[wave * 16 + i][lane];
+  const long long f = f0 + lane;
+  if (f < frames) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int col = c0 + wave * 16 + i;
+      if (col < M) out[(long long)col * out_ld + out_frame0 + f] = v[i];
+    }
+  }
+}
+
+hipError_t launch_transpose_slab(const void* slab, long long frames, int M, void* out, long long out_ld,
+                                 long long out_frame0, int elem_bytes, hipStream_t s) {
+  if (frames <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((frames + 63) / 64)), block(256);
+  if (elem_bytes == 8)
+    hipLaunchKernelGGL(pfb_transpose_slab_kernel<float2>, grid, block, 0, s, (const float2*)slab, frames, M, (float2*)out,
+                       out_ld, out_frame0);
+  else
+    hipLaunchKernelGGL(pfb_transpose_slab_kernel<float>, grid, block, 0, s, (const float*)slab, frames, M, (float*)out,
+                       out_ld, out_frame0);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
 // 1 read : 2 write streaming copy (same byte mix as int16 -> complex64, D = M)
 
 __global__ void __launch_bounds__(256) pfb_stream_copy_kernel(const uint4* in, uint4* out, long long n) {

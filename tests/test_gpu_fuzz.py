@@ -64,6 +64,9 @@ def test_fused_kernels_agree_with_the_generic_kernel(case):
             ch.set_option(L.PFB_OPT_TILE_WAVES, int(rng.choice([4, 6, 8, 16])))
         if rng.random() < 0.3:
             ch.set_option(L.PFB_OPT_XCD_REMAP, int(rng.integers(0, 2)))
+        if kw["channel_major"] and rng.random() < 0.3:   # frame-major slabs + transpose instead of the fused stores
+            ch.set_option(L.PFB_OPT_SCHEDULE, 9)
+            ch.set_option(L.PFB_OPT_SLAB_FRAMES, int(rng.choice([0, 64, 192, 1024])))
         parts = [ch(iq[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
         assert ch.last_kernel.startswith("pfb_fast")
         axis = 1 if kw["channel_major"] else 0

@@ -157,6 +157,45 @@ def test_channel_major_device_path_is_bit_identical_to_frame_major():
         assert torch.equal(torch.cat([p_ for p_ in parts if p_.numel()], dim=1), cm)
 
 
+@pytest.mark.parametrize("M,P,D,fmt,bw,routes", [
+    (64, 12, 64, "int16", 12, ((0, 0), (2, 0), (8, 8), (8, 16), (8, 32), (9, 64), (9, 0))),
+    (64, 12, 64, "int8", 8, ((8, 16), (9, 192))),
+    (56, 12, 56, "int16", 12, ((0, 0), (8, 16), (9, 128))),
+    (128, 12, 64, "int16", 12, ((2, 0), (8, 8), (8, 16), (9, 64))),
+    (256, 8, 256, "int8", 8, ((0, 0), (8, 8), (9, 64))),
+    (32, 12, 32, "int16", 12, ((8, 32), (9, 64))),
+    (1024, 16, 1024, "int16", 12, ((-1, 0), (9, 64), (9, 192))),
+    (560, 12, 560, "int16", 12, ((-1, 0), (9, 128))),
+    (20, 12, 20, "int16", 12, ((0, 0), (9, 64)))])
+def test_channel_major_routes_are_bit_identical(M, P, D, fmt, bw, routes):
+    """Channel-major output by every route -- the kernel's own stores (schedules 0 and 2), short runs transposed in LDS
+    (schedule 8; frames_per_block = frames per wave), frame-major slabs + the transpose kernel (schedule 9) -- with and
+    without fused abs(), over a stream cut into calls: the transposed frame-major result, bit for bit."""
+    import torch
+    n = D * 1500 + 11
+    iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device="cuda")
+    h = np.random.default_rng(6).standard_normal(M * P).astype(np.float32) / M
+    cuts = [0, D * 700 + 5, D * 701, n]
+    for mag in (False, True):
+        kw = dict(taps=h, decimation=D, sample_format=fmt, bit_width=bw, magnitude=mag, fftshift=True, derotate=(D != M))
+        with Channelizer(M, **kw) as a:
+            want = a(iq).T.contiguous()
+        for sched, arg in routes:
+            with Channelizer(M, channel_major=True, **kw) as b:
+                if sched >= 0:
+                    b.set_option(L.PFB_OPT_SCHEDULE, sched)
+                if sched == 8:
+                    b.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, arg)
+                    b.set_option(L.PFB_OPT_TILE_WAVES, {8: 4, 16: 4, 32: 2}[arg])
+                if sched == 9:
+                    b.set_option(L.PFB_OPT_SLAB_FRAMES, arg)
+                got = b(iq)
+                assert torch.equal(got, want), (M, mag, sched, arg)
+                b.reset()
+                parts = [b(iq[s:e]) for s, e in zip(cuts[:-1], cuts[1:])]
+                assert torch.equal(torch.cat([q for q in parts if q.numel()], dim=1), want), (M, mag, sched, arg)
+
+
 @pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (128, 12, 64, "int16", 12), (56, 12, 56, "int16", 12),
                                           (256, 8, 256, "int8", 8), (560, 12, 560, "int16", 12), (16, 12, 16, "int16", 12),
                                           (20, 12, 20, "int16", 12), (40, 12, 40, "int16", 12)])

@@ -19,8 +19,9 @@ from sdr_channelizer_amd import Channelizer, design_prototype, synth  # noqa: E4
 from sdr_channelizer_amd import _lib as L  # noqa: E402
 
 OPT = {"kernel": L.PFB_OPT_KERNEL, "fpb": L.PFB_OPT_FRAMES_PER_BLOCK, "nt": L.PFB_OPT_NONTEMPORAL,
-       "remap": L.PFB_OPT_XCD_REMAP, "sched": L.PFB_OPT_SCHEDULE, "grid": L.PFB_OPT_GRID, "tw": L.PFB_OPT_TILE_WAVES, "exp": L.PFB_OPT_EXPERIMENT, "var": L.PFB_OPT_VARIANT}
-DEFAULTS = {"kernel": 2, "fpb": 0, "nt": 0, "remap": -1, "sched": -1, "grid": 0, "tw": 8, "exp": 0, "var": 0}
+       "remap": L.PFB_OPT_XCD_REMAP, "sched": L.PFB_OPT_SCHEDULE, "grid": L.PFB_OPT_GRID, "tw": L.PFB_OPT_TILE_WAVES, "exp": L.PFB_OPT_EXPERIMENT, "var": L.PFB_OPT_VARIANT,
+       "slab": L.PFB_OPT_SLAB_FRAMES}
+DEFAULTS = {"kernel": 2, "fpb": 0, "nt": 0, "remap": -1, "sched": -1, "grid": 0, "tw": 8, "exp": 0, "var": 0, "slab": 0}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2-samples", type=int, default=30)
