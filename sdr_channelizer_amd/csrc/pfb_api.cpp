@@ -4,6 +4,10 @@
 // host-pointer staging path and the state blob.  All arithmetic is in
 // pfb_kernels.hip; there is deliberately no CPU implementation here.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -552,31 +556,60 @@ int pfb_process(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t c
   return process_host(h, iq, n, out, f);
 }
 
+namespace {
+
+// read exactly `bytes` at `offset` of fd into dst with `nthreads` concurrent pread streams (one thread copies out
+// of the page cache at ~7 GB/s, less than PCIe takes; four keep the link busy)
+bool pread_parallel(int fd, char* dst, size_t bytes, off_t offset, int nthreads) {
+  auto read_range = [fd](char* d, size_t len, off_t off) {
+    while (len > 0) {
+      const ssize_t r = ::pread(fd, d, len, off);
+      if (r <= 0) return false;
+      d += r; len -= (size_t)r; off += r;
+    }
+    return true;
+  };
+  if (nthreads <= 1 || bytes < ((size_t)4 << 20)) return read_range(dst, bytes, offset);
+  const size_t part = ((bytes / (size_t)nthreads) + 4095) & ~(size_t)4095;
+  std::vector<std::thread> th;
+  std::vector<char> ok((size_t)nthreads, 1);
+  for (int t = 0; t < nthreads; ++t) {
+    const size_t lo = std::min(bytes, part * (size_t)t), hi = std::min(bytes, part * (size_t)(t + 1));
+    if (hi > lo) th.emplace_back([&, t, lo, hi] { ok[(size_t)t] = read_range(dst + lo, hi - lo, offset + (off_t)lo); });
+  }
+  for (auto& x : th) x.join();
+  for (char c : ok) if (!c) return false;
+  return true;
+}
+
+}  // namespace
+
 int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap, uint64_t* frames_out,
                         pfb_iq_info* info_out) {
   if (!h || !path) return PFB_ERR_BAD_ARG;
   if (h->layout != PFB_LAYOUT_FRAME_MAJOR) return PFB_ERR_UNSUPPORTED;
-  FILE* f = std::fopen(path, "rb");
-  if (!f) { g_detail = std::string("cannot open ") + path; return PFB_ERR_BAD_ARG; }
+  const int fd = ::open(path, O_RDONLY);
+  if (fd < 0) { g_detail = std::string("cannot open ") + path; return PFB_ERR_BAD_ARG; }
   unsigned char head[PFB_IQ_HEADER_BYTES];
-  const size_t got = std::fread(head, 1, sizeof(head), f);
+  const ssize_t got = ::pread(fd, head, sizeof(head), 0);
   pfb_iq_info info;
-  int rc = pfb_iq_parse_header(head, got, &info);
+  int rc = pfb_iq_parse_header(head, got > 0 ? (size_t)got : 0, &info);
   if (rc == PFB_OK && ((int)info.sample_format != h->fmt || (int)info.packet.bitWidth != h->bit_width))
     rc = PFB_ERR_BAD_FORMAT;  // the handle's scale / unpack would not match this record
   if (rc == PFB_OK) {
-    std::fseek(f, 0, SEEK_END);
-    const long long payload = (long long)std::ftell(f) - (long long)info.header_bytes;
-    if (payload != (long long)info.packet.numSamples * (long long)info.bytes_per_sample) rc = PFB_ERR_BAD_FORMAT;
+    struct stat st;
+    const long long size = ::fstat(fd, &st) == 0 ? (long long)st.st_size : -1;
+    if (size - (long long)info.header_bytes != (long long)info.packet.numSamples * (long long)info.bytes_per_sample)
+      rc = PFB_ERR_BAD_FORMAT;
   }
   if (info_out) *info_out = info;
-  if (rc != PFB_OK) { std::fclose(f); return rc; }
+  if (rc != PFB_OK) { ::close(fd); return rc; }
   const uint64_t n = info.packet.numSamples;
   const uint64_t need = frames_for(h, n);
   if (frames_out) *frames_out = need;
-  if (need > cap) { std::fclose(f); return PFB_ERR_CAPACITY; }
-  if (need > 0 && !out) { std::fclose(f); return PFB_ERR_BAD_ARG; }
-  // Two page-locked chunk buffers: a reader thread fills one from the file while the other crosses PCIe and is
+  if (need > cap) { ::close(fd); return PFB_ERR_CAPACITY; }
+  if (need > 0 && !out) { ::close(fd); return PFB_ERR_BAD_ARG; }
+  // Two page-locked chunk buffers: reader threads fill one from the file while the other crosses PCIe and is
   // transformed (the staged host path overlaps its own copy-in / transform / copy-out underneath).
   const uint64_t chunk = (((uint64_t)1 << 24) / h->D) * h->D;  // whole frames, 64 MB of int16 I/Q
   const size_t chunk_bytes = (size_t)std::min<uint64_t>(chunk, n ? n : 1) * h->bps;
@@ -584,20 +617,27 @@ int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap
   if (!bufs[0] || !bufs[1]) {
     pfb_host_free(bufs[0]);
     pfb_host_free(bufs[1]);
-    std::fclose(f);
+    ::close(fd);
     return PFB_ERR_NO_MEMORY;
   }
-  std::fseek(f, (long)info.header_bytes, SEEK_SET);
-  auto read_chunk = [&](char* dst, uint64_t m) { return std::fread(dst, (size_t)h->bps, (size_t)m, f) == (size_t)m; };
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int readers = (int)std::max(1u, std::min(4u, hw ? hw / 2 : 1u));
+  auto read_chunk = [&](char* dst, uint64_t first, uint64_t m) {
+    return pread_parallel(fd, dst, (size_t)m * h->bps, (off_t)info.header_bytes + (off_t)(first * h->bps), readers);
+  };
+  // four staging steps per chunk, so that the copy-in / transform / copy-out pipeline of the host path has stages
+  // to overlap inside each call (measured: 3.3 -> 3.7 GS/s; larger file chunks lose more at the ends than they gain)
+  const int64_t user_host_chunk = h->opt_host_chunk;
+  if (user_host_chunk <= 0) h->opt_host_chunk = (int64_t)1 << 22;
   uint64_t done = 0, frames_done = 0;
-  bool have = n > 0 && read_chunk(bufs[0], std::min<uint64_t>(chunk, n));
+  bool have = n > 0 && read_chunk(bufs[0], 0, std::min<uint64_t>(chunk, n));
   if (n > 0 && !have) rc = PFB_ERR_BAD_FORMAT;
   for (uint64_t i = 0; done < n && rc == PFB_OK; ++i) {
     const uint64_t m = std::min<uint64_t>(chunk, n - done);
     const uint64_t m_next = std::min<uint64_t>(chunk, n - done - m);
     bool next_ok = true;
     std::thread reader;
-    if (m_next > 0) reader = std::thread([&, i, m_next] { next_ok = read_chunk(bufs[(i + 1) & 1], m_next); });
+    if (m_next > 0) reader = std::thread([&, i, m_next] { next_ok = read_chunk(bufs[(i + 1) & 1], done + m, m_next); });
     uint64_t fr = 0;
     rc = pfb_process(h, bufs[i & 1], m, static_cast<char*>(out) + frames_done * h->M * h->out_elem, cap - frames_done, &fr,
                      PFB_MEM_HOST);
@@ -606,9 +646,10 @@ int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap
     done += m;
     frames_done += fr;
   }
+  h->opt_host_chunk = user_host_chunk;
   pfb_host_free(bufs[0]);
   pfb_host_free(bufs[1]);
-  std::fclose(f);
+  ::close(fd);
   if (frames_out) *frames_out = frames_done;
   return rc;
 }

@@ -20,6 +20,9 @@ iqfile.write_iq(path, iq, fs=56e6, fc=915e6, bit_width=12)
 try:
     with Channelizer(M, taps=design_prototype(M, P), bit_width=12, fftshift=True) as ch:
         out = pinned_empty((n // M, M), np.complex64)
+        if len(sys.argv) > 2:
+            from sdr_channelizer_amd import _lib as L
+            ch.set_option(L.PFB_OPT_HOST_CHUNK_SAMPLES, 1 << int(sys.argv[2]))
         for rep in range(3):
             ch.reset()
             t0 = time.perf_counter()
