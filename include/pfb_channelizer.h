@@ -141,7 +141,8 @@ int pfb_frames_for(const pfb_handle* h, uint64_t num_samples, uint64_t* frames_o
  * matlab/convert_my_iq_to_mat.m:102) and that the handle was created for its sample format and
  * bit width, then stream the payload through the GPU in chunks without holding the file in
  * memory.  Replaces convert_my_iq_to_mat.m:40-118 + the load/normalise lines of the channelizer
- * scripts for the common case.  `out` is host memory, frame-major layout only.  The handle's state
+ * scripts for the common case.  `out` is host memory; a channel-major handle fills one M x frames
+ * matrix for the whole record (column stride = the record's frame count).  The handle's state
  * carries over exactly as with pfb_process (call pfb_reset first for a fresh channelizer per file,
  * create_pdws_channelized.m:33). */
 int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t out_capacity_frames,

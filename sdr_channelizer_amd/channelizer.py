@@ -222,7 +222,8 @@ class Channelizer:
 
     def process_iq_file(self, path: str, reset: bool = True, out=None):
         """Channelize one .iq record straight from disk (header parsed and checked by the library).
-        Returns (y, info): y is (frames, M) complex64 (or float32 with magnitude=True).  ``out``: optional numpy
+        Returns (y, info): y is (frames, M) complex64 (or float32 with magnitude=True), (M, frames) for a
+        channel-major handle.  ``out``: optional numpy
         buffer with room for frames * M values (page-locked, see pinned_empty, for the full rate)."""
         from . import iqfile
         with open(path, "rb") as f:
@@ -231,17 +232,18 @@ class Channelizer:
             self.reset()  # a fresh channelizer per file, create_pdws_channelized.m:33
         F = self.frames_for(int(info.packet.numSamples))
         dt = np.float32 if self.magnitude else np.complex64
+        shape = (self.num_bands, F) if self.channel_major else (F, self.num_bands)
         if out is None:
-            res = np.empty((F, self.num_bands), dtype=dt)
+            res = np.empty(shape, dtype=dt)
         else:
             if out.dtype != dt or out.size < F * self.num_bands or not out.flags.c_contiguous:
                 raise ValueError("out must be a C-contiguous array of the output dtype with room for frames*M values")
-            res = out.reshape(-1)[: F * self.num_bands].reshape(F, self.num_bands)
+            res = out.reshape(-1)[: F * self.num_bands].reshape(shape)
         f_out = C.c_uint64()
         got = L.PfbIqInfo()
         L.check(self._lib.pfb_process_iq_file(self._h, path.encode(), C.c_void_p(res.ctypes.data), F, C.byref(f_out),
                                               C.byref(got)), "pfb_process_iq_file")
-        return res[: f_out.value], got
+        return (res if self.channel_major else res[: f_out.value]), got
 
     def sync(self) -> None:
         L.check(self._lib.pfb_sync(self._h), "pfb_sync")

@@ -275,7 +275,10 @@ int ensure_stage(pfb_handle* h, size_t in_bytes, size_t out_bytes, bool both_set
   return PFB_OK;
 }
 
-int process_host(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t frames_total) {
+// channel-major: `out` is the whole M x out_ld matrix and this call fills rows [out_row0, out_row0 + frames_total) of
+// every column (pfb_process: out_ld = frames_total, out_row0 = 0; the .iq front end walks out_row0 through a record)
+int process_host(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t frames_total, uint64_t out_ld,
+                 uint64_t out_row0) {
   // Stage through device buffers in chunks (multiples of D so chunks never change the carried phase
   // pattern mid-call beyond what the stream semantics already define).  Three streams and two buffer
   // sets: chunk i+1 is copied in while chunk i is transformed and chunk i-1 is copied out, so a caller
@@ -324,7 +327,7 @@ int process_host(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t 
         HIP_TRY(hipMemcpyAsync(dst + frames_done * h->M * h->out_elem, st_out[b], (size_t)f * h->M * h->out_elem,
                                hipMemcpyDeviceToHost, h->s_out));
       } else {  // column k of this chunk -> rows [frames_done, frames_done+f) of column k of the call
-        HIP_TRY(hipMemcpy2DAsync(dst + frames_done * h->out_elem, (size_t)frames_total * h->out_elem, st_out[b],
+        HIP_TRY(hipMemcpy2DAsync(dst + (out_row0 + frames_done) * h->out_elem, (size_t)out_ld * h->out_elem, st_out[b],
                                  (size_t)f * h->out_elem, (size_t)f * h->out_elem, (size_t)h->M, hipMemcpyDeviceToHost,
                                  h->s_out));
       }
@@ -553,7 +556,7 @@ int pfb_process(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t c
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PFB_OK;
   }
-  return process_host(h, iq, n, out, f);
+  return process_host(h, iq, n, out, f, f, 0);
 }
 
 namespace {
@@ -587,7 +590,6 @@ bool pread_parallel(int fd, char* dst, size_t bytes, off_t offset, int nthreads)
 int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap, uint64_t* frames_out,
                         pfb_iq_info* info_out) {
   if (!h || !path) return PFB_ERR_BAD_ARG;
-  if (h->layout != PFB_LAYOUT_FRAME_MAJOR) return PFB_ERR_UNSUPPORTED;
   const int fd = ::open(path, O_RDONLY);
   if (fd < 0) { g_detail = std::string("cannot open ") + path; return PFB_ERR_BAD_ARG; }
   unsigned char head[PFB_IQ_HEADER_BYTES];
@@ -638,9 +640,14 @@ int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap
     bool next_ok = true;
     std::thread reader;
     if (m_next > 0) reader = std::thread([&, i, m_next] { next_ok = read_chunk(bufs[(i + 1) & 1], done + m, m_next); });
-    uint64_t fr = 0;
-    rc = pfb_process(h, bufs[i & 1], m, static_cast<char*>(out) + frames_done * h->M * h->out_elem, cap - frames_done, &fr,
-                     PFB_MEM_HOST);
+    const uint64_t fr = frames_for(h, m);
+    {
+      DeviceGuard g(h->device);
+      if (h->layout == PFB_LAYOUT_FRAME_MAJOR)
+        rc = process_host(h, bufs[i & 1], m, static_cast<char*>(out) + frames_done * h->M * h->out_elem, fr, fr, 0);
+      else  // channel-major: one M x `need` matrix for the whole record, this chunk fills rows frames_done...
+        rc = process_host(h, bufs[i & 1], m, out, fr, need, frames_done);
+    }
     if (reader.joinable()) reader.join();
     if (rc == PFB_OK && !next_ok) rc = PFB_ERR_BAD_FORMAT;
     done += m;

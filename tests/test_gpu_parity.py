@@ -592,6 +592,18 @@ def test_iq_file_front_end(oracle, tmp_path):
         y, info = ch.process_iq_file(path)
         assert info.packet.numSamples == iq.shape[0] and info.file_format == 2
         assert rel(y, oracle_run(oracle, iq, h, M, P, M, 12, fftshift=True)) < REL_TOL
+    with Channelizer(M, taps=h, bit_width=12, fftshift=True, channel_major=True) as cm:   # one M x F matrix per record
+        y_cm, _ = cm.process_iq_file(path)
+        assert y_cm.shape == (M, y.shape[0]) and np.array_equal(y_cm, y.T)
+    big = np.tile(iq[: M * 3000], (200, 1))                 # 38 M samples: three 2^24-sample file chunks, four staging steps each
+    big_path = os.path.join(tmp_path, iqfile.filename_for(1_700_000_000_456))
+    iqfile.write_iq(big_path, big, fs=56e6, fc=2.4e9, bit_width=12)
+    with Channelizer(M, taps=h, bit_width=12) as ch, Channelizer(M, taps=h, bit_width=12, channel_major=True) as cm:
+        y_big, _ = ch.process_iq_file(big_path)
+        ch.reset()
+        assert np.array_equal(y_big, ch(big))               # the same stream in one call from memory
+        y_big_cm, _ = cm.process_iq_file(big_path)
+        assert np.array_equal(y_big_cm, y_big.T)
     with Channelizer(M, taps=h, bit_width=16) as ch16:      # record says 12-bit
         with pytest.raises(PfbError) as e:
             ch16.process_iq_file(path)
