@@ -276,6 +276,18 @@ int pfb_pdw_extract_raw(const void* iq, uint64_t num_samples, uint32_t sample_fo
                         double fs, double fc, double sample_start_time, double snr_threshold_db,
                         double trailing_threshold_db, pfb_pdw* out, uint64_t capacity, uint64_t* count,
                         double* noise_floor_out, uint32_t mem, int32_t device_id, void* hip_stream);
+/* One iteration of the loop in matlab/create_pdws_channelized.m:22-143 -- load a record, channelize
+ * it, fftshift (the handle's PFB_FLAG_FFTSHIFT), extract its PDWs -- in one call: the payload is
+ * streamed to the GPU as in pfb_process_iq_file, the F x M channel matrix stays in device memory
+ * (scratch kept on the handle, freed with it) and only the PDWs come back.  fs, fc and the sample
+ * start time are the record's (sampleRateSps, frequencyHz, sampleStartTime: the values
+ * convert_my_iq_to_mat.m stores in the .mat the script loads).  The handle must be frame-major with
+ * complex output and match the record's format and bit width; its state carries over as with
+ * pfb_process (pfb_reset first for a fresh channelizer per file, :33).  Remaining arguments as in
+ * pfb_pdw_extract. */
+int pfb_pdw_from_iq_file(pfb_handle* h, const char* path, double snr_threshold_db, uint32_t flags,
+                         pfb_pdw* out, uint64_t capacity, uint64_t* count, double* noise_floor_out,
+                         pfb_iq_info* info_out);
 /* Text of the most recent HIP failure inside pfb_pdw_extract on this thread. */
 const char* pfb_pdw_last_error_detail(void);
 /* How the last pfb_pdw_extract on this thread found the noise floors: 1 = sampled bracket + one

@@ -94,6 +94,8 @@ struct pfb_handle {
   int64_t opt_slab_frames = 0;  // channel-major by slabs: frames per slab (0 = ~32 MiB of output)
   void* d_slab = nullptr;       // frame-major scratch of the slab path
   size_t slab_bytes = 0;
+  void* d_matrix = nullptr;     // pfb_pdw_from_iq_file: the record's channel matrix (grow-only)
+  size_t matrix_bytes = 0;
   const char* last_kernel = "";
   // host staging: two sets, so chunk i+1 crosses PCIe inbound while chunk i is transformed and chunk i-1 goes out
   void* d_stage_in = nullptr;   // set 0 (also pfb_prime's scratch)
@@ -125,6 +127,7 @@ void free_handle(pfb_handle* h) {
   (void)hipFree(h->d_stage_in2);
   (void)hipFree(h->d_stage_out2);
   (void)hipFree(h->d_slab);
+  (void)hipFree(h->d_matrix);
   if (h->s_in) (void)hipStreamDestroy(h->s_in);
   if (h->s_out) (void)hipStreamDestroy(h->s_out);
   for (int i = 0; i < 2; ++i) {
@@ -277,8 +280,11 @@ int ensure_stage(pfb_handle* h, size_t in_bytes, size_t out_bytes, bool both_set
 
 // channel-major: `out` is the whole M x out_ld matrix and this call fills rows [out_row0, out_row0 + frames_total) of
 // every column (pfb_process: out_ld = frames_total, out_row0 = 0; the .iq front end walks out_row0 through a record)
+// device_out: `out` is device memory (frame-major rows follow each other; channel-major as above): nothing is
+// copied back and the call returns once the input has left the host buffer, the kernels still queued on the
+// handle's stream.
 int process_host(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t frames_total, uint64_t out_ld,
-                 uint64_t out_row0) {
+                 uint64_t out_row0, bool device_out = false) {
   // Stage through device buffers in chunks (multiples of D so chunks never change the carried phase
   // pattern mid-call beyond what the stream semantics already define).  Three streams and two buffer
   // sets: chunk i+1 is copied in while chunk i is transformed and chunk i-1 is copied out, so a caller
@@ -288,8 +294,10 @@ int process_host(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t 
   chunk = ((chunk + h->D - 1) / h->D) * h->D;
   const uint64_t max_frames = chunk / h->D + 1;
   const int rc = ensure_stage(h, (size_t)std::min<uint64_t>(chunk, n ? n : 1) * h->bps,
-                              (size_t)std::min<uint64_t>(max_frames, frames_total ? frames_total : 1) * h->M *
-                                  sizeof(float2), true);
+                              device_out ? 0
+                                         : (size_t)std::min<uint64_t>(max_frames, frames_total ? frames_total : 1) * h->M *
+                                               sizeof(float2),
+                              true);
   if (rc != PFB_OK) return rc;
   if (!h->s_in) {
     HIP_TRY(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
@@ -317,6 +325,17 @@ int process_host(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t 
     HIP_TRY(hipMemcpyAsync(st_in[b], src + done * h->bps, (size_t)m * h->bps, hipMemcpyHostToDevice, h->s_in));
     HIP_TRY(hipEventRecord(h->ev_in[b], h->s_in));
     HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_in[b], 0));
+    if (device_out) {
+      if (h->layout == PFB_LAYOUT_FRAME_MAJOR)
+        rc2 = enqueue(h, st_in[b], m, dst + frames_done * h->M * h->out_elem, f, (int64_t)f, 0);
+      else
+        rc2 = enqueue(h, st_in[b], m, dst, f, (int64_t)out_ld, (int64_t)(out_row0 + frames_done));
+      if (rc2 != PFB_OK) break;
+      HIP_TRY(hipEventRecord(h->ev_k[b], h->stream));
+      done += m;
+      frames_done += f;
+      continue;
+    }
     if (i >= 2) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_out[b], 0));  // chunk i-2 has left this output buffer
     rc2 = enqueue(h, st_in[b], m, st_out[b], f, (int64_t)f, 0);
     if (rc2 != PFB_OK) break;
@@ -337,6 +356,7 @@ int process_host(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t 
     frames_done += f;
   }
   HIP_TRY(hipStreamSynchronize(h->s_in));
+  if (device_out) return rc2;
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipStreamSynchronize(h->s_out));
   return rc2;
@@ -587,39 +607,40 @@ bool pread_parallel(int fd, char* dst, size_t bytes, off_t offset, int nthreads)
 
 }  // namespace
 
-int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap, uint64_t* frames_out,
-                        pfb_iq_info* info_out) {
-  if (!h || !path) return PFB_ERR_BAD_ARG;
+namespace {
+
+// open a record, parse and check its header against the handle (format, bit width, payload length)
+int open_record(pfb_handle* h, const char* path, int* fd_out, pfb_iq_info* info) {
   const int fd = ::open(path, O_RDONLY);
   if (fd < 0) { g_detail = std::string("cannot open ") + path; return PFB_ERR_BAD_ARG; }
   unsigned char head[PFB_IQ_HEADER_BYTES];
   const ssize_t got = ::pread(fd, head, sizeof(head), 0);
-  pfb_iq_info info;
-  int rc = pfb_iq_parse_header(head, got > 0 ? (size_t)got : 0, &info);
-  if (rc == PFB_OK && ((int)info.sample_format != h->fmt || (int)info.packet.bitWidth != h->bit_width))
+  int rc = pfb_iq_parse_header(head, got > 0 ? (size_t)got : 0, info);
+  if (rc == PFB_OK && ((int)info->sample_format != h->fmt || (int)info->packet.bitWidth != h->bit_width))
     rc = PFB_ERR_BAD_FORMAT;  // the handle's scale / unpack would not match this record
   if (rc == PFB_OK) {
     struct stat st;
     const long long size = ::fstat(fd, &st) == 0 ? (long long)st.st_size : -1;
-    if (size - (long long)info.header_bytes != (long long)info.packet.numSamples * (long long)info.bytes_per_sample)
+    if (size - (long long)info->header_bytes != (long long)info->packet.numSamples * (long long)info->bytes_per_sample)
       rc = PFB_ERR_BAD_FORMAT;
   }
-  if (info_out) *info_out = info;
   if (rc != PFB_OK) { ::close(fd); return rc; }
+  *fd_out = fd;
+  return PFB_OK;
+}
+
+// Stream the record's payload through the channelizer.  Two page-locked chunk buffers: reader threads fill one
+// from the file while the other crosses PCIe and is transformed (the staged host path overlaps its own copy-in /
+// transform / copy-out underneath).  device_out: `out` is device memory and nothing comes back.
+int stream_record(pfb_handle* h, int fd, const pfb_iq_info& info, void* out, uint64_t need, bool device_out,
+                  uint64_t* frames_out) {
   const uint64_t n = info.packet.numSamples;
-  const uint64_t need = frames_for(h, n);
-  if (frames_out) *frames_out = need;
-  if (need > cap) { ::close(fd); return PFB_ERR_CAPACITY; }
-  if (need > 0 && !out) { ::close(fd); return PFB_ERR_BAD_ARG; }
-  // Two page-locked chunk buffers: reader threads fill one from the file while the other crosses PCIe and is
-  // transformed (the staged host path overlaps its own copy-in / transform / copy-out underneath).
   const uint64_t chunk = (((uint64_t)1 << 24) / h->D) * h->D;  // whole frames, 64 MB of int16 I/Q
   const size_t chunk_bytes = (size_t)std::min<uint64_t>(chunk, n ? n : 1) * h->bps;
   char* bufs[2] = {static_cast<char*>(pfb_host_alloc(chunk_bytes)), static_cast<char*>(pfb_host_alloc(chunk_bytes))};
   if (!bufs[0] || !bufs[1]) {
     pfb_host_free(bufs[0]);
     pfb_host_free(bufs[1]);
-    ::close(fd);
     return PFB_ERR_NO_MEMORY;
   }
   const unsigned hw = std::thread::hardware_concurrency();
@@ -631,6 +652,7 @@ int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap
   // to overlap inside each call (measured: 3.3 -> 3.7 GS/s; larger file chunks lose more at the ends than they gain)
   const int64_t user_host_chunk = h->opt_host_chunk;
   if (user_host_chunk <= 0) h->opt_host_chunk = (int64_t)1 << 22;
+  int rc = PFB_OK;
   uint64_t done = 0, frames_done = 0;
   bool have = n > 0 && read_chunk(bufs[0], 0, std::min<uint64_t>(chunk, n));
   if (n > 0 && !have) rc = PFB_ERR_BAD_FORMAT;
@@ -644,9 +666,9 @@ int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap
     {
       DeviceGuard g(h->device);
       if (h->layout == PFB_LAYOUT_FRAME_MAJOR)
-        rc = process_host(h, bufs[i & 1], m, static_cast<char*>(out) + frames_done * h->M * h->out_elem, fr, fr, 0);
+        rc = process_host(h, bufs[i & 1], m, static_cast<char*>(out) + frames_done * h->M * h->out_elem, fr, fr, 0, device_out);
       else  // channel-major: one M x `need` matrix for the whole record, this chunk fills rows frames_done...
-        rc = process_host(h, bufs[i & 1], m, out, fr, need, frames_done);
+        rc = process_host(h, bufs[i & 1], m, out, fr, need, frames_done, device_out);
     }
     if (reader.joinable()) reader.join();
     if (rc == PFB_OK && !next_ok) rc = PFB_ERR_BAD_FORMAT;
@@ -656,9 +678,59 @@ int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap
   h->opt_host_chunk = user_host_chunk;
   pfb_host_free(bufs[0]);
   pfb_host_free(bufs[1]);
-  ::close(fd);
   if (frames_out) *frames_out = frames_done;
   return rc;
+}
+
+}  // namespace
+
+int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap, uint64_t* frames_out,
+                        pfb_iq_info* info_out) {
+  if (!h || !path) return PFB_ERR_BAD_ARG;
+  int fd = -1;
+  pfb_iq_info info;
+  int rc = open_record(h, path, &fd, &info);
+  if (info_out) *info_out = info;
+  if (rc != PFB_OK) return rc;
+  const uint64_t need = frames_for(h, info.packet.numSamples);
+  if (frames_out) *frames_out = need;
+  if (need > cap) { ::close(fd); return PFB_ERR_CAPACITY; }
+  if (need > 0 && !out) { ::close(fd); return PFB_ERR_BAD_ARG; }
+  rc = stream_record(h, fd, info, out, need, false, frames_out);
+  ::close(fd);
+  return rc;
+}
+
+int pfb_pdw_from_iq_file(pfb_handle* h, const char* path, double snr_threshold_db, uint32_t pdw_flags, pfb_pdw* out,
+                         uint64_t capacity, uint64_t* count, double* noise_floor_out, pfb_iq_info* info_out) {
+  if (!h || !path || !count || (capacity > 0 && !out)) return PFB_ERR_BAD_ARG;
+  // the PDW stage reads a frame-major complex matrix (mag = abs(iq), phase = angle(iq), :67-68)
+  if (h->layout != PFB_LAYOUT_FRAME_MAJOR || (h->flags & PFB_FLAG_MAGNITUDE)) return PFB_ERR_UNSUPPORTED;
+  int fd = -1;
+  pfb_iq_info info;
+  int rc = open_record(h, path, &fd, &info);
+  if (info_out) *info_out = info;
+  if (rc != PFB_OK) return rc;
+  const uint64_t need = frames_for(h, info.packet.numSamples);
+  const size_t bytes = (size_t)std::max<uint64_t>(need, 1) * h->M * sizeof(float2);
+  {
+    DeviceGuard g(h->device);
+    if (bytes > h->matrix_bytes) {
+      if (hipStreamSynchronize(h->stream) != hipSuccess) { ::close(fd); return PFB_ERR_HIP; }
+      (void)hipFree(h->d_matrix);
+      h->d_matrix = nullptr; h->matrix_bytes = 0;
+      if (hipMalloc(&h->d_matrix, bytes) != hipSuccess) { (void)hipGetLastError(); ::close(fd); return PFB_ERR_NO_MEMORY; }
+      h->matrix_bytes = bytes;
+    }
+  }
+  uint64_t frames = 0;
+  rc = stream_record(h, fd, info, h->d_matrix, need, true, &frames);
+  ::close(fd);
+  if (rc != PFB_OK) return rc;
+  // the kernels are queued on the handle's stream; the extraction runs behind them on the same stream
+  return pfb_pdw_extract(h->d_matrix, frames, (uint32_t)h->M, (uint32_t)h->D, (double)info.packet.sampleRateSps,
+                         (double)info.packet.frequencyHz, info.packet.sampleStartTime, snr_threshold_db, pdw_flags, out,
+                         capacity, count, noise_floor_out, PFB_MEM_DEVICE, h->device, h->stream);
 }
 
 uint64_t pfb_history_samples(const pfb_handle* h) { return h ? (uint64_t)h->hist_samples : 0; }

@@ -54,6 +54,31 @@ def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decima
     return (out[:n], nf) if return_noise_floor else out[:n]
 
 
+def pdws_from_iq_file(channelizer, path: str, *, snr_threshold_db: float = 15.0, matlab_quirks: bool = True,
+                      capacity: int = 1 << 20, reset: bool = True, return_noise_floor: bool = False):
+    """One iteration of create_pdws_channelized.m:22-143 in one call (pfb_pdw_from_iq_file): the record at ``path``
+    is streamed through ``channelizer`` (a frame-major, complex-output Channelizer matching the record), the channel
+    matrix stays on the GPU, the PDWs come back.  fs, fc and the start time are the record's.  Returns (pdws, info)
+    or (pdws, noise_floor, info)."""
+    lib = L.load()
+    if reset:
+        channelizer.reset()  # a fresh channelizer per file, create_pdws_channelized.m:33
+    out = np.zeros(capacity, dtype=PDW_DTYPE)
+    nf = np.zeros(channelizer.num_bands, dtype=np.float64)
+    count = C.c_uint64(0)
+    info = L.PfbIqInfo()
+    rc = lib.pfb_pdw_from_iq_file(channelizer._h, path.encode(), float(snr_threshold_db),
+                                  L.PFB_PDW_MATLAB_QUIRKS if matlab_quirks else 0, out.ctypes.data_as(C.POINTER(L.PfbPdw)),
+                                  capacity, C.byref(count), nf.ctypes.data_as(C.POINTER(C.c_double)), C.byref(info))
+    if rc != L.PFB_OK:
+        detail = lib.pfb_pdw_last_error_detail().decode()
+        raise L.PfbError(rc, "pfb_pdw_from_iq_file" + (f" [{detail}]" if detail else ""))
+    n = int(count.value)
+    if n > capacity:
+        raise OverflowError(f"{n} pulses found, capacity {capacity}")
+    return (out[:n], nf, info) if return_noise_floor else (out[:n], info)
+
+
 def extract_pdws_raw(iq, fs: float, fc: float, sample_start_time: float, *, bit_width: int = 12,
                      snr_threshold_db: float = 18.0, trailing_threshold_db: float = 3.0, capacity: int = 1 << 20,
                      return_noise_floor: bool = False, device: int = -1):

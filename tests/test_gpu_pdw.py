@@ -150,6 +150,40 @@ def test_config5_end_to_end(oracle):
     assert bool(torch.isfinite(torch.view_as_real(y)).all())
 
 
+def test_record_to_pdws_in_one_call(oracle, tmp_path):
+    """pfb_pdw_from_iq_file = one iteration of create_pdws_channelized.m:22-143 (record -> channelizer -> fftshift ->
+    PDWs) with the channel matrix left on the GPU: the same PDWs, bit for bit, as the two-step path (record -> host
+    matrix -> pfb_pdw_extract), and the oracle's; fs / fc / start time come from the record's header."""
+    import os
+    from sdr_channelizer_amd import iqfile, PfbError
+    from sdr_channelizer_amd import _lib as L
+    from sdr_channelizer_amd.pdw import pdws_from_iq_file
+    M, P, fs, fc, t0 = 56, 12, 56_000_000, 915_000_000, 1.7e9 + 0.25
+    n = M * 400_000 + 17                            # 22.4 M samples: two file chunks, several staging steps each
+    iq = synth.pulsed_iq_numpy(n, 12, np.int16, seed=12)
+    path = os.path.join(tmp_path, iqfile.filename_for(1_700_000_000_250))
+    iqfile.write_iq(path, iq, fs=fs, fc=fc, bit_width=12, start_time=t0)
+    h = oracle.design_prototype(M, P).astype(np.float32)
+    with Channelizer(M, taps=h, bit_width=12, fftshift=True) as ch:
+        got, nf, info = pdws_from_iq_file(ch, path, return_noise_floor=True)
+        assert info.packet.sampleRateSps == fs and info.packet.sampleStartTime == t0
+        y, _ = ch.process_iq_file(path)
+        two_step, nf2 = extract_pdws(y, fs, fc, t0, matlab_quirks=True, return_noise_floor=True)
+        assert len(got) >= 300 and np.array_equal(got, two_step) and np.array_equal(nf, nf2)
+        again, _ = pdws_from_iq_file(ch, path)      # scratch reused, state reset per file
+        assert np.array_equal(again, got)
+        want = oracle.extract_pdws(y.astype(np.complex128), fs, fc, t0, 15.0, matlab_quirks=True, max_out=1 << 18)
+        compare(got, want, fs / M)
+    with Channelizer(M, taps=h, bit_width=12, magnitude=True) as chm:      # needs the complex matrix
+        with pytest.raises(PfbError) as e:
+            pdws_from_iq_file(chm, path)
+        assert e.value.status == L.PFB_ERR_UNSUPPORTED
+    with Channelizer(M, taps=h, bit_width=16) as ch16:                     # record says 12-bit
+        with pytest.raises(PfbError) as e:
+            pdws_from_iq_file(ch16, path)
+        assert e.value.status == L.PFB_ERR_BAD_FORMAT
+
+
 # ---- raw stream (matlab/create_pdws.m) ------------------------------------------------------------------
 
 def raw_stream(n, dtype, bw, seed, cf32=False, noise=0.004):

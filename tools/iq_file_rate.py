@@ -29,6 +29,12 @@ try:
             y, info = ch.process_iq_file(path, out=out)
             dt = time.perf_counter() - t0
             print(f".iq file -> channels: {n / dt / 1e6:8.1f} MS/s ({n * 4 / dt / 1e9:5.2f} GB/s of file, {dt * 1e3:.1f} ms for 2^{n.bit_length() - 1} samples)")
+        from sdr_channelizer_amd.pdw import pdws_from_iq_file
+        for rep in range(3):
+            t0 = time.perf_counter()
+            pdws, info = pdws_from_iq_file(ch, path)
+            dt = time.perf_counter() - t0
+            print(f".iq file -> PDWs (matrix stays on the GPU): {n / dt / 1e6:8.1f} MS/s ({n * 4 / dt / 1e9:5.2f} GB/s of file, {dt * 1e3:.1f} ms, {len(pdws)} pulses)")
 finally:
     os.remove(path)
     os.rmdir(d)
