@@ -252,7 +252,10 @@ enum {
   /* reproduce the reference's two indexing quirks: the unshifted centre-frequency list is
    * indexed with the shifted column (:42 vs :80) and phase(toa:jj) linear-indexes column 1
    * (:114).  Without the flag the pulse's own column and its true centre frequency are used. */
-  PFB_PDW_MATLAB_QUIRKS = 1u << 0
+  PFB_PDW_MATLAB_QUIRKS = 1u << 0,
+  /* `y` is channel-major, y[k*frames + m]: MATLAB's own column-major F x M matrix (what pfb_process
+   * writes for a PFB_LAYOUT_CHANNEL_MAJOR handle).  Transposed once into device scratch. */
+  PFB_PDW_CHANNEL_MAJOR = 1u << 1
 };
 
 /* fs_in: sample rate BEFORE decimation; the frame rate used is fs_in/decimation (:62).

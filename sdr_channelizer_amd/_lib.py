@@ -55,6 +55,7 @@ class PfbPdw(C.Structure):
 
 
 PFB_PDW_MATLAB_QUIRKS = 1
+PFB_PDW_CHANNEL_MAJOR = 2
 
 
 class PfbIqInfo(C.Structure):

@@ -32,6 +32,11 @@
 
 #include "pfb_channelizer.h"
 
+namespace pfb {  // pfb_kernels.hip
+hipError_t launch_transpose_slab(const void* slab, long long frames, int M, void* out, long long out_ld,
+                                 long long out_frame0, int elem_bytes, hipStream_t s);
+}
+
 namespace {
 
 constexpr int kTile = 512;        // smallest tile of the edge scan, in frames (tiles grow with the stream, see tile_words_for)
@@ -1261,6 +1266,7 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
   {
     size_t need = 0;
     if (mem == PFB_MEM_HOST) need += padded((size_t)F * M * sizeof(float2));
+    if (flags & PFB_PDW_CHANNEL_MAJOR) need += padded((size_t)F * M * sizeof(float2));
     need += padded(2 * (size_t)M * 256 * sizeof(unsigned)) + 2 * padded(2 * M * sizeof(unsigned)) + 2 * padded(sizeof(unsigned));
     need += 4 * padded(2 * M * sizeof(unsigned long long)) + padded((size_t)kUndecided * sizeof(unsigned long long));
     need += padded(cand_elems * sizeof(double)) + padded(M * sizeof(double));
@@ -1273,6 +1279,14 @@ extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, ui
     d_y = own;
   } else {
     d_y = static_cast<const float2*>(y_in);
+  }
+  if (flags & PFB_PDW_CHANNEL_MAJOR) {
+    // MATLAB's own layout (M columns of F frames): the pipeline walks rows of M channels, so the matrix is
+    // transposed once into scratch (64 x 64 tiles through LDS, 512-byte reads and writes)
+    if (F >= (1ll << 31)) return PFB_ERR_UNSUPPORTED;
+    float2* fm = take<float2>(ws, (size_t)F * M);
+    PDW_TRY(pfb::launch_transpose_slab(d_y, (long long)M, (int)F, fm, (long long)M, 0, (int)sizeof(float2), st));
+    d_y = fm;
   }
   d_hist = take<unsigned>(ws, 2 * (size_t)M * 256);  // [select][channel][digit]; the sample runs two selects at once
   d_bucket = take<unsigned>(ws, 2 * (size_t)M);

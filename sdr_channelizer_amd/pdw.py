@@ -17,29 +17,30 @@ PDW_DTYPE = np.dtype([("toa", "f8"), ("freq", "f8"), ("pw", "f8"), ("snr", "f8")
 
 def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decimation: int | None = None,
                  snr_threshold_db: float = 15.0, matlab_quirks: bool = True, capacity: int = 1 << 20,
-                 return_noise_floor: bool = False, device: int = -1):
+                 return_noise_floor: bool = False, device: int = -1, channel_major: bool = False):
     """y: (frames, M) complex64, frame-major, fftshift-ed -- a numpy array or a torch CUDA tensor
-    (used in place).  Returns a structured numpy array with PDW_DTYPE, in the reference's order
+    (used in place); with channel_major=True y is (M, frames), MATLAB's own layout of the same matrix (what a
+    channel-major Channelizer returns).  Returns a structured numpy array with PDW_DTYPE, in the reference's order
     (channels outermost, time within a channel)."""
     lib = L.load()
     is_torch = type(y).__module__.startswith("torch")
     if is_torch and y.is_cuda:
         if not y.is_contiguous() or y.dim() != 2:
             raise ValueError("need a contiguous (frames, M) complex64 tensor")
-        frames, M = int(y.shape[0]), int(y.shape[1])
+        frames, M = (int(y.shape[1]), int(y.shape[0])) if channel_major else (int(y.shape[0]), int(y.shape[1]))
         ptr, mem, keep = C.c_void_p(y.data_ptr()), L.PFB_MEM_DEVICE, y
         import torch
         stream = C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)
         device = y.device.index
     else:
         a = np.ascontiguousarray(np.asarray(y), dtype=np.complex64)
-        frames, M = a.shape
+        frames, M = a.shape[::-1] if channel_major else a.shape
         ptr, mem, keep, stream = C.c_void_p(a.ctypes.data), L.PFB_MEM_HOST, a, C.c_void_p(0)
     out = np.zeros(capacity, dtype=PDW_DTYPE)
     assert out.dtype.itemsize == C.sizeof(L.PfbPdw)
     nf = np.zeros(M, dtype=np.float64)
     count = C.c_uint64(0)
-    flags = L.PFB_PDW_MATLAB_QUIRKS if matlab_quirks else 0
+    flags = (L.PFB_PDW_MATLAB_QUIRKS if matlab_quirks else 0) | (L.PFB_PDW_CHANNEL_MAJOR if channel_major else 0)
     rc = lib.pfb_pdw_extract(ptr, frames, M, M if decimation is None else int(decimation), float(fs_in), float(fc),
                              float(sample_start_time), float(snr_threshold_db), flags,
                              out.ctypes.data_as(C.POINTER(L.PfbPdw)), capacity, C.byref(count),

@@ -78,6 +78,16 @@ def test_synthetic_pulses_match_oracle(oracle, quirks):
     assert got["sat"][got["bin"] == 0].all() and not got["sat"][got["bin"] == 3].any()
 
 
+def test_channel_major_input_gives_the_same_pdws():
+    """PFB_PDW_CHANNEL_MAJOR: MATLAB's own layout of the matrix (M columns of F frames), host and device input."""
+    import torch
+    y = synthetic_matrix(F=5003, M=70, seed=5)
+    want, nf = extract_pdws(y, 7e6, 1e9, 5.0, return_noise_floor=True)
+    for ycm in (np.ascontiguousarray(y.T), torch.from_numpy(y).cuda().T.contiguous()):
+        got, nf_cm = extract_pdws(ycm, 7e6, 1e9, 5.0, return_noise_floor=True, channel_major=True)
+        assert len(got) > 5 and np.array_equal(got, want) and np.array_equal(nf_cm, nf)
+
+
 def test_odd_frame_count_and_device_input(oracle):
     import torch
     y = synthetic_matrix(F=4097, M=70, seed=3)   # odd F (plain median), M not a multiple of 64
