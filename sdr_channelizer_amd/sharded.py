@@ -8,6 +8,11 @@ halo is raw input, not a partial result.  One process per GPU; the transport is
 ``torch.distributed`` point-to-point (backend "nccl" = RCCL over xGMI on the GPU box,
 "gloo" in the CPU tests).  Message size is tiny (61 KB at M=1024, P=16), so this is
 latency- not bandwidth-bound.
+
+The reference's own batch job -- the loop over a folder of records in
+matlab/create_pdws_channelized.m:22-143 -- shards by RECORD instead: every record gets a fresh
+channelizer (:33), so ranks take whole files and nothing is exchanged but the PDW lists at the end
+(``records_for_rank``, ``pdws_from_folder``).
 """
 from __future__ import annotations
 
@@ -81,3 +86,31 @@ class ShardedChannelizer:
                 self.ch.prime(halo)
         self.ch.set_frame_index(first_frame)
         return self.ch(segment, out=out)
+
+
+def records_for_rank(paths, rank: int, world: int) -> list[str]:
+    """The records rank ``rank`` processes: sorted (the recorder's file names sort by time), dealt round-robin so
+    that every rank's share spans the whole capture."""
+    return sorted(paths)[rank::world]
+
+
+def pdws_from_folder(channelizer, paths, rank: int = 0, world: int = 1, group=None, gather: bool = True, **kw):
+    """create_pdws_channelized.m's loop over a folder, one process per GPU: this rank's records go through
+    ``pdw.pdws_from_iq_file`` (record -> channelizer -> PDWs, matrix on the GPU); with gather=True every rank gets the
+    PDWs of all records concatenated in file order -- the script's accumulated ``pdw`` struct -- via one
+    all_gather_object (the only collective; PDW lists are small).  Returns (pdws, [(path, count), ...])."""
+    import numpy as np
+    from .pdw import PDW_DTYPE, pdws_from_iq_file
+    mine = []
+    for path in records_for_rank(paths, rank, world):
+        pdws, _info = pdws_from_iq_file(channelizer, path, **kw)
+        mine.append((path, pdws))
+    if world > 1 and gather:
+        import torch.distributed as dist
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine, group=group)
+        mine = [item for part in everyone for item in part]
+    mine.sort(key=lambda item: item[0])
+    parts = [p for _, p in mine]
+    allp = np.concatenate(parts) if parts else np.zeros(0, dtype=PDW_DTYPE)
+    return allp, [(path, len(p)) for path, p in mine]

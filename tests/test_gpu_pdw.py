@@ -194,6 +194,29 @@ def test_record_to_pdws_in_one_call(oracle, tmp_path):
         assert e.value.status == L.PFB_ERR_BAD_FORMAT
 
 
+def test_folder_of_records_like_the_scripts_loop(tmp_path):
+    """sharded.pdws_from_folder on one rank = create_pdws_channelized.m's loop: per-record PDWs concatenated in file
+    order (what the script accumulates); a two-way split of the same folder holds the same PDWs."""
+    import os
+    from sdr_channelizer_amd import iqfile
+    from sdr_channelizer_amd.pdw import pdws_from_iq_file
+    from sdr_channelizer_amd.sharded import pdws_from_folder
+    M, fs, fc = 56, 56_000_000, 915_000_000
+    paths = []
+    for i in range(3):
+        iq = synth.pulsed_iq_numpy(M * 30_000, 12, np.int16, seed=50 + i)
+        paths.append(os.path.join(tmp_path, iqfile.filename_for(1_700_000_000_000 + 1000 * i)))
+        iqfile.write_iq(paths[-1], iq, fs=fs, fc=fc, bit_width=12, start_time=1.7e9 + i)
+    with Channelizer(M, bit_width=12, fftshift=True) as ch:
+        allp, listing = pdws_from_folder(ch, paths[::-1])
+        each = [pdws_from_iq_file(ch, p)[0] for p in paths]
+        assert [p for p, _ in listing] == paths and [c for _, c in listing] == [len(e) for e in each]
+        assert len(allp) > 30 and np.array_equal(allp, np.concatenate(each))
+        halves = [pdws_from_folder(ch, paths, r, 2, gather=False)[0] for r in range(2)]
+        assert sum(len(h_) for h_ in halves) == len(allp)
+        assert np.array_equal(halves[0], np.concatenate([each[0], each[2]])) and np.array_equal(halves[1], each[1])
+
+
 # ---- raw stream (matlab/create_pdws.m) ------------------------------------------------------------------
 
 def raw_stream(n, dtype, bw, seed, cf32=False, noise=0.004):

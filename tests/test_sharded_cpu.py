@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 from oracle.pfb_oracle import COracle, OracleConfig
 from sdr_channelizer_amd import synth
-from sdr_channelizer_amd.sharded import ShardedChannelizer, exchange_halo, segment_bounds
+from sdr_channelizer_amd.sharded import ShardedChannelizer, exchange_halo, records_for_rank, segment_bounds
 
 M, P, D, BW = 16, 4, 8, 12
 
@@ -93,3 +93,49 @@ def test_two_rank_time_sharding_matches_single_stream():
     assert np.array_equal(sharded, single)  # raw-sample halo => identical bits
     for r in range(world):  # ring: each rank holds its predecessor's tail
         assert np.array_equal(ret[r][1], ret[(r - 1) % world][2])
+
+
+def _folder_worker(rank, world, port, paths, ret):
+    """pdws_from_folder with the per-record extraction stubbed (no GPU here): the sharding and the gather are what
+    is under test."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sdr_channelizer_amd.pdw as pdw_mod
+        from sdr_channelizer_amd.sharded import pdws_from_folder
+
+        def fake(ch, path, **kw):  # a record's "PDWs": toa = its index in the folder, one entry per (index + 1)
+            i = int(os.path.basename(path).split("_")[1].split(".")[0])
+            out = np.zeros(i + 1, dtype=pdw_mod.PDW_DTYPE)
+            out["toa"] = i
+            out["bin"] = rank
+            return out, None
+
+        pdw_mod.pdws_from_iq_file = fake
+        allp, listing = pdws_from_folder(None, paths, rank, world)
+        ret[rank] = (allp.copy(), listing)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_records_for_rank_partitions_the_folder():
+    paths = [f"rec_{i:03d}.iq" for i in (5, 1, 4, 0, 3, 2, 6)]
+    shares = [records_for_rank(paths, r, 3) for r in range(3)]
+    assert shares[0] == ["rec_000.iq", "rec_003.iq", "rec_006.iq"] and shares[2] == ["rec_002.iq", "rec_005.iq"]
+    assert sorted(p for s_ in shares for p in s_) == sorted(paths)
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_record_sharding_gathers_every_records_pdws_in_file_order():
+    world = 2
+    paths = [f"/data/rec_{i:03d}.iq" for i in (3, 0, 4, 1, 2)]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_folder_worker, args=(world, _free_port(), paths, ret), nprocs=world, join=True)
+    for r in range(world):
+        allp, listing = ret[r]
+        assert [os.path.basename(p) for p, _ in listing] == [f"rec_{i:03d}.iq" for i in range(5)]
+        assert [c for _, c in listing] == [1, 2, 3, 4, 5]
+        assert np.array_equal(allp["toa"], np.repeat(np.arange(5), np.arange(1, 6)))
+        assert np.array_equal(allp["bin"], np.repeat(np.arange(5) % world, np.arange(1, 6)))  # who processed which record
