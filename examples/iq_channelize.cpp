@@ -1,7 +1,9 @@
 // iq_channelize.cpp -- C++ host loop over the C ABI, shaped like the recorders' loop body
 // (/root/reference/cpp/blade_record_iq_12bit.cpp:287-325: one dwell buffer per iteration, blocking,
 // status ints, caller-owned buffers).  Reads .iq records (header + interleaved int payload), channelizes
-// each with libpfb_channelizer.so and writes <name>.chan (raw complex64, frame-major F x M).
+// each with libpfb_channelizer.so and writes <name>.chan (raw complex64, frame-major F x M), then runs the rest of
+// create_pdws_channelized.m's loop body in one call (pfb_pdw_from_iq_file: record -> channels -> PDWs, the matrix
+// never leaving the GPU) and writes <name>.pdw (pfb_pdw structs).
 //
 //   hipcc -O2 -Iinclude examples/iq_channelize.cpp -Lsdr_channelizer_amd -lpfb_channelizer \
 //         -Wl,-rpath,$PWD/sdr_channelizer_amd -o examples/iq_channelize
@@ -79,6 +81,20 @@ int main(int argc, char** argv) {
                 info.packet.bitWidth, (unsigned long long)frames, M, fs_out, pfb_last_kernel(ch));
     std::ofstream fout(std::string(argv[a]) + ".chan", std::ofstream::binary);
     fout.write((const char*)out.data(), (std::streamsize)(out.size() * sizeof(out[0])));
+
+    // create_pdws_channelized.m:64-143 on the same record (snrThreshold 15 dB, the script's indexing quirks kept)
+    std::vector<pfb_pdw> pdws(1 << 16);
+    uint64_t count = 0;
+    pfb_reset(ch);
+    status = pfb_pdw_from_iq_file(ch, argv[a], 15.0, PFB_PDW_MATLAB_QUIRKS, pdws.data(), pdws.size(), &count, nullptr, nullptr);
+    if (status != PFB_OK) {
+      std::printf("PDW extraction failed: %s (%s)\n", pfb_strerror(status), pfb_pdw_last_error_detail());
+      continue;
+    }
+    if (count > pdws.size()) count = pdws.size();
+    std::printf("%s: %llu PDWs\n", argv[a], (unsigned long long)count);
+    std::ofstream fpdw(std::string(argv[a]) + ".pdw", std::ofstream::binary);
+    fpdw.write((const char*)pdws.data(), (std::streamsize)(count * sizeof(pfb_pdw)));
   }
   if (ch) pfb_destroy(ch);
   return status;

@@ -638,7 +638,7 @@ def test_cpp_host_loop_without_python(oracle, tmp_path):
         iqfile.write_iq(path, iq, fs=56e6, fc=915e6, bit_width=bw, marker=marker)
         recs.append((path, iq, "int8" if dt == np.int8 else "int16", bw))
     out = subprocess.run([exe, str(M), str(P)] + [r[0] for r in recs], check=True, capture_output=True, text=True).stdout
-    assert out.count("frames x 64 channels") == 2 and "pfb_fast<M64" in out
+    assert out.count("frames x 64 channels") == 2 and "pfb_fast<M64" in out and out.count(" PDWs") == 2
     h = oracle.design_prototype(M, P).astype(np.float32)   # the same Kaiser design pfb_design_prototype makes
     for path, iq, fmt, bw in recs:
         got = np.fromfile(path + ".chan", dtype=np.complex64).reshape(-1, M)
@@ -646,3 +646,8 @@ def test_cpp_host_loop_without_python(oracle, tmp_path):
             want = ch(iq)
         assert got.shape == want.shape
         assert rel(got, want) < 2e-6   # taps designed in C (float) vs by the oracle (double, then rounded)
+        # ... and the PDWs of the same record, extracted by the C++ process in one call
+        from sdr_channelizer_amd.pdw import PDW_DTYPE, extract_pdws
+        pdws = np.fromfile(path + ".pdw", dtype=PDW_DTYPE)
+        ref_pdws = extract_pdws(got, 56e6, 915e6, 0.0)
+        assert len(pdws) == len(ref_pdws) > 0 and np.array_equal(pdws, ref_pdws)
