@@ -291,6 +291,12 @@ int pfb_pdw_extract_raw(const void* iq, uint64_t num_samples, uint32_t sample_fo
 int pfb_pdw_from_iq_file(pfb_handle* h, const char* path, double snr_threshold_db, uint32_t flags,
                          pfb_pdw* out, uint64_t capacity, uint64_t* count, double* noise_floor_out,
                          pfb_iq_info* info_out);
+/* One iteration of the loop in matlab/create_pdws.m (load a record, :30-105 on its raw stream):
+ * the payload goes to the device through page-locked chunks, pfb_pdw_extract_raw runs there, the PDWs
+ * come back.  fs, fc, bit width and start time are the record's. */
+int pfb_pdw_raw_from_iq_file(const char* path, double snr_threshold_db, double trailing_threshold_db,
+                             pfb_pdw* out, uint64_t capacity, uint64_t* count, double* noise_floor_out,
+                             pfb_iq_info* info_out, int32_t device_id);
 /* Text of the most recent HIP failure inside pfb_pdw_extract on this thread. */
 const char* pfb_pdw_last_error_detail(void);
 /* How the last pfb_pdw_extract on this thread found the noise floors: 1 = sampled bracket + one

@@ -71,7 +71,7 @@ EXPORTS = (
     "pfb_frames_for", "pfb_history_samples", "pfb_prime", "pfb_get_state", "pfb_set_state", "pfb_set_frame_index",
     "pfb_get_frame_index", "pfb_center_frequencies", "pfb_design_prototype", "pfb_strerror",
     "pfb_last_error_detail", "pfb_abi_version", "pfb_device_count", "pfb_set_option", "pfb_last_kernel",
-    "pfb_measure_stream_copy", "pfb_get_kernel_times", "pfb_host_alloc", "pfb_host_free", "pfb_pdw_extract", "pfb_pdw_extract_raw", "pfb_pdw_from_iq_file", "pfb_pdw_last_error_detail", "pfb_pdw_release_workspace", "pfb_pdw_last_noise_floor_path",
+    "pfb_measure_stream_copy", "pfb_get_kernel_times", "pfb_host_alloc", "pfb_host_free", "pfb_pdw_extract", "pfb_pdw_extract_raw", "pfb_pdw_from_iq_file", "pfb_pdw_raw_from_iq_file", "pfb_pdw_last_error_detail", "pfb_pdw_release_workspace", "pfb_pdw_last_noise_floor_path",
     "pfb_iq_parse_header", "pfb_iq_fill_packet", "pfb_iq_filename",
 )
 
@@ -139,6 +139,9 @@ def load() -> C.CDLL:
     lib.pfb_pdw_from_iq_file.argtypes = [vp, C.c_char_p, C.c_double, u32, C.POINTER(PfbPdw), u64, C.POINTER(u64),
                                          C.POINTER(C.c_double), C.POINTER(PfbIqInfo)]
     lib.pfb_pdw_from_iq_file.restype = C.c_int
+    lib.pfb_pdw_raw_from_iq_file.argtypes = [C.c_char_p, C.c_double, C.c_double, C.POINTER(PfbPdw), u64, C.POINTER(u64),
+                                             C.POINTER(C.c_double), C.POINTER(PfbIqInfo), C.c_int32]
+    lib.pfb_pdw_raw_from_iq_file.restype = C.c_int
     lib.pfb_pdw_extract_raw.argtypes = [vp, u64, u32, u32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                         C.POINTER(PfbPdw), u64, C.POINTER(u64), C.POINTER(C.c_double), u32, i32, vp]
     lib.pfb_pdw_last_error_detail.restype = C.c_char_p

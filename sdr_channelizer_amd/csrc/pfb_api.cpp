@@ -609,14 +609,14 @@ bool pread_parallel(int fd, char* dst, size_t bytes, off_t offset, int nthreads)
 
 namespace {
 
-// open a record, parse and check its header against the handle (format, bit width, payload length)
+// open a record, parse and check its header (payload length; format and bit width against the handle, if any)
 int open_record(pfb_handle* h, const char* path, int* fd_out, pfb_iq_info* info) {
   const int fd = ::open(path, O_RDONLY);
   if (fd < 0) { g_detail = std::string("cannot open ") + path; return PFB_ERR_BAD_ARG; }
   unsigned char head[PFB_IQ_HEADER_BYTES];
   const ssize_t got = ::pread(fd, head, sizeof(head), 0);
   int rc = pfb_iq_parse_header(head, got > 0 ? (size_t)got : 0, info);
-  if (rc == PFB_OK && ((int)info->sample_format != h->fmt || (int)info->packet.bitWidth != h->bit_width))
+  if (rc == PFB_OK && h && ((int)info->sample_format != h->fmt || (int)info->packet.bitWidth != h->bit_width))
     rc = PFB_ERR_BAD_FORMAT;  // the handle's scale / unpack would not match this record
   if (rc == PFB_OK) {
     struct stat st;
@@ -731,6 +731,71 @@ int pfb_pdw_from_iq_file(pfb_handle* h, const char* path, double snr_threshold_d
   return pfb_pdw_extract(h->d_matrix, frames, (uint32_t)h->M, (uint32_t)h->D, (double)info.packet.sampleRateSps,
                          (double)info.packet.frequencyHz, info.packet.sampleStartTime, snr_threshold_db, pdw_flags, out,
                          capacity, count, noise_floor_out, PFB_MEM_DEVICE, h->device, h->stream);
+}
+
+int pfb_pdw_raw_from_iq_file(const char* path, double snr_threshold_db, double trailing_threshold_db, pfb_pdw* out,
+                             uint64_t capacity, uint64_t* count, double* noise_floor_out, pfb_iq_info* info_out,
+                             int32_t device_id) {
+  if (!path || !count || (capacity > 0 && !out)) return PFB_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return PFB_ERR_NO_DEVICE; }
+  int dev = device_id;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if (dev >= ndev) return PFB_ERR_BAD_ARG;
+  int fd = -1;
+  pfb_iq_info info;
+  int rc = open_record(nullptr, path, &fd, &info);
+  if (info_out) *info_out = info;
+  if (rc != PFB_OK) return rc;
+  DeviceGuard g(dev);
+  const uint64_t n = info.packet.numSamples;
+  const size_t bps = info.bytes_per_sample;
+  if (n == 0) { ::close(fd); return PFB_ERR_BAD_ARG; }
+  // the record goes to the device through two page-locked 64 MB buffers: four pread streams fill one while the
+  // other crosses PCIe; the extraction then runs on the device-resident stream
+  void* d_iq = nullptr;
+  hipStream_t st = nullptr;
+  const size_t chunk = (size_t)64 << 20;
+  char* bufs[2] = {static_cast<char*>(pfb_host_alloc(std::min(chunk, n * bps))),
+                   static_cast<char*>(pfb_host_alloc(std::min(chunk, n * bps)))};
+  auto cleanup = [&] {
+    pfb_host_free(bufs[0]);
+    pfb_host_free(bufs[1]);
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(d_iq);
+    ::close(fd);
+  };
+  if (!bufs[0] || !bufs[1] || hipMalloc(&d_iq, n * bps) != hipSuccess || hipStreamCreate(&st) != hipSuccess) {
+    (void)hipGetLastError();
+    cleanup();
+    return PFB_ERR_NO_MEMORY;
+  }
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int readers = (int)std::max(1u, std::min(4u, hw ? hw / 2 : 1u));
+  const size_t total = n * bps;
+  auto read_chunk = [&](char* dst, size_t first, size_t len) {
+    return pread_parallel(fd, dst, len, (off_t)info.header_bytes + (off_t)first, readers);
+  };
+  bool ok = read_chunk(bufs[0], 0, std::min(chunk, total));
+  size_t done = 0;
+  for (size_t i = 0; done < total && ok; ++i) {
+    const size_t len = std::min(chunk, total - done), next = std::min(chunk, total - done - len);
+    bool next_ok = true;
+    std::thread reader;
+    if (next > 0) reader = std::thread([&, i, next] { next_ok = read_chunk(bufs[(i + 1) & 1], done + len, next); });
+    const hipError_t e = hipMemcpyAsync(static_cast<char*>(d_iq) + done, bufs[i & 1], len, hipMemcpyHostToDevice, st);
+    const hipError_t e2 = hipStreamSynchronize(st);
+    if (reader.joinable()) reader.join();
+    if (e != hipSuccess || e2 != hipSuccess) { cleanup(); return hip_fail(e != hipSuccess ? e : e2, "pfb_pdw_raw_from_iq_file"); }
+    ok = next_ok;
+    done += len;
+  }
+  if (!ok) { cleanup(); return PFB_ERR_BAD_FORMAT; }
+  rc = pfb_pdw_extract_raw(d_iq, n, info.sample_format, info.packet.bitWidth, (double)info.packet.sampleRateSps,
+                           (double)info.packet.frequencyHz, info.packet.sampleStartTime, snr_threshold_db,
+                           trailing_threshold_db, out, capacity, count, noise_floor_out, PFB_MEM_DEVICE, dev, st);
+  cleanup();
+  return rc;
 }
 
 uint64_t pfb_history_samples(const pfb_handle* h) { return h ? (uint64_t)h->hist_samples : 0; }

@@ -80,6 +80,27 @@ def pdws_from_iq_file(channelizer, path: str, *, snr_threshold_db: float = 15.0,
     return (out[:n], nf, info) if return_noise_floor else (out[:n], info)
 
 
+def raw_pdws_from_iq_file(path: str, *, snr_threshold_db: float = 18.0, trailing_threshold_db: float = 3.0,
+                          capacity: int = 1 << 20, return_noise_floor: bool = False, device: int = -1):
+    """One iteration of create_pdws.m's loop (pfb_pdw_raw_from_iq_file): the record's raw stream -> PDWs, with fs, fc,
+    bit width and start time from its header.  Returns (pdws, info) or (pdws, noise_floor, info)."""
+    lib = L.load()
+    out = np.zeros(capacity, dtype=PDW_DTYPE)
+    nf = C.c_double(0.0)
+    count = C.c_uint64(0)
+    info = L.PfbIqInfo()
+    rc = lib.pfb_pdw_raw_from_iq_file(path.encode(), float(snr_threshold_db), float(trailing_threshold_db),
+                                      out.ctypes.data_as(C.POINTER(L.PfbPdw)), capacity, C.byref(count), C.byref(nf),
+                                      C.byref(info), int(device))
+    if rc != L.PFB_OK:
+        detail = lib.pfb_pdw_last_error_detail().decode()
+        raise L.PfbError(rc, "pfb_pdw_raw_from_iq_file" + (f" [{detail}]" if detail else ""))
+    n = int(count.value)
+    if n > capacity:
+        raise OverflowError(f"{n} pulses found, capacity {capacity}")
+    return (out[:n], nf.value, info) if return_noise_floor else (out[:n], info)
+
+
 def extract_pdws_raw(iq, fs: float, fc: float, sample_start_time: float, *, bit_width: int = 12,
                      snr_threshold_db: float = 18.0, trailing_threshold_db: float = 3.0, capacity: int = 1 << 20,
                      return_noise_floor: bool = False, device: int = -1):

@@ -296,6 +296,29 @@ def test_raw_stream_at_recorder_size(oracle):
     compare(got, want, 56e6)
 
 
+def test_raw_record_to_pdws_in_one_call(tmp_path):
+    """pfb_pdw_raw_from_iq_file = one iteration of create_pdws.m's loop: the same PDWs as extract_pdws_raw on the
+    record's payload with the header's fs / fc / bit width / start time; int16 and int8 records."""
+    import os
+    from sdr_channelizer_amd import iqfile, PfbError
+    from sdr_channelizer_amd import _lib as L
+    from sdr_channelizer_amd.pdw import raw_pdws_from_iq_file
+    for dt, bw, n, noise, snr in ((np.int16, 12, 40_000_003, 0.004, 18.0), (np.int8, 8, 3_000_001, 0.012, 12.0)):   # 160 MB: three 64 MB chunks
+        iq, _ = raw_stream(n, dt, bw, seed=bw, noise=noise)
+        path = os.path.join(tmp_path, iqfile.filename_for(1_700_000_000_000 + bw))
+        iqfile.write_iq(path, iq, fs=20e6, fc=2.4e9, bit_width=bw, start_time=1.7e9 + 0.5)
+        got, nf, info = raw_pdws_from_iq_file(path, snr_threshold_db=snr, return_noise_floor=True)
+        want, want_nf = extract_pdws_raw(iq, 20e6, 2.4e9, 1.7e9 + 0.5, bit_width=bw, snr_threshold_db=snr,
+                                         return_noise_floor=True)
+        assert info.packet.numSamples == n and len(got) >= 5
+        assert np.array_equal(got, want) and nf == want_nf
+    with open(path, "r+b") as f:
+        f.truncate(os.path.getsize(path) - 2)
+    with pytest.raises(PfbError) as e:
+        raw_pdws_from_iq_file(path)
+    assert e.value.status == L.PFB_ERR_BAD_FORMAT
+
+
 def test_raw_stream_argument_checks_and_silence(oracle):
     from sdr_channelizer_amd import _lib as L
     iq = np.zeros((1000, 2), np.int16)
