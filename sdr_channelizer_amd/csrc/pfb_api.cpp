@@ -727,6 +727,10 @@ int pfb_pdw_from_iq_file(pfb_handle* h, const char* path, double snr_threshold_d
   rc = stream_record(h, fd, info, h->d_matrix, need, true, &frames);
   ::close(fd);
   if (rc != PFB_OK) return rc;
+  if (frames == 0) {  // a record shorter than one frame holds no pulse
+    *count = 0;
+    return PFB_OK;
+  }
   // the kernels are queued on the handle's stream; the extraction runs behind them on the same stream
   return pfb_pdw_extract(h->d_matrix, frames, (uint32_t)h->M, (uint32_t)h->D, (double)info.packet.sampleRateSps,
                          (double)info.packet.frequencyHz, info.packet.sampleStartTime, snr_threshold_db, pdw_flags, out,

@@ -122,8 +122,9 @@ def test_switches(oracle, M, P, D, kw):
                                           (56, 12, 56, "int16", 12), (560, 12, 560, "int16", 12), (8, 12, 8, "int16", 12),
                                           (20, 12, 20, "int16", 12)])
 def test_channel_major_layout(oracle, M, P, D, fmt, bw):
-    """PFB_LAYOUT_CHANNEL_MAJOR = MATLAB's column-major F x M.  Every fused shape has a channel-major
-    instantiation of its sliding-run kernel; (16, 4, 8) has no fused path and takes the generic kernel."""
+    """PFB_LAYOUT_CHANNEL_MAJOR = MATLAB's column-major F x M.  Every fused shape writes it: transposed
+    in LDS inside the kernel, by the kernel's own stores, or from frame-major slabs (M = 1024, 560); (16, 4, 8) has
+    no fused path and takes the generic kernel."""
     iq = synth.pulsed_iq_numpy(D * 333, bw, np.int8 if fmt == "int8" else np.int16, seed=5)
     h = oracle.design_prototype(M, P).astype(np.float32)
     with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, channel_major=True, fftshift=True,
