@@ -67,6 +67,7 @@ struct pfb_handle {
   int fmt = 0, bit_width = 0, layout = 0;
   unsigned flags = 0;
   int device = 0;
+  int num_cus = 256;       // compute units of the device (slab sizing)
   int bps = 0;             // bytes per input sample
   int out_elem = 8;        // bytes per output element: complex64, or float32 with PFB_FLAG_MAGNITUDE
   int hist_samples = 0;    // M*P + D
@@ -211,7 +212,7 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
       const int bmod = ((p.base % cpt) + cpt) % cpt;
       p.vec_ok = (bmod == 0) && (reinterpret_cast<uintptr_t>(d_iq) % (uintptr_t)(h->bps * cpt) == 0);
       if (by_slabs) {
-        long long sf = h->opt_slab_frames > 0 ? h->opt_slab_frames : 256ll * fpb;  // one run per CU
+        long long sf = h->opt_slab_frames > 0 ? h->opt_slab_frames : (long long)h->num_cus * fpb;  // one run per CU
         sf = std::max<long long>(64, (sf + 63) / 64 * 64);
         sf = std::max<long long>(sf, (h->hist_samples + h->D - 1) / h->D + 1);  // a later slab's window reaches back into the input, never into the history
         sf = std::min<long long>(sf, ((long long)frames + 63) / 64 * 64);
@@ -482,6 +483,11 @@ int pfb_create(const pfb_config* cfg, pfb_handle** out) {
   h->fast = pfb::find_fast_kernel(h->M, h->P, h->D, h->fmt, 0);
 
   DeviceGuard g(dev);
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->num_cus = cus;
+    else (void)hipGetLastError();
+  }
   const size_t L = (size_t)M * P, L_given = (size_t)M * P_given;
   std::vector<float> taps(L, 0.0f);
   const float scale = std::ldexp(1.0f, -(bw - 1));  // power of two: h*scale is exact
