@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) pdw_hist_kernel(const float2* y, long lon
   for (int i = threadIdx.x; i < 256 * 64; i += 256) {
     const int d = i >> 6, c = i & 63;
     const unsigned v = h[d][c];
-    if (v && blockIdx.x * 64 + c < M) atomicAdd(&hist[(size_t)(blockIdx.x * 64 + c) * 256 + d], v);
+    if (v && (int)(blockIdx.x * 64) + c < M) atomicAdd(&hist[(size_t)(blockIdx.x * 64 + c) * 256 + d], v);
   }
 }
 
