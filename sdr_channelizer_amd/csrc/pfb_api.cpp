@@ -197,6 +197,9 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
       int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
       fpb = ((fpb + c - 1) / c) * c;
       p.schedule = (h->opt_schedule >= 0 && h->opt_schedule != 9) ? h->opt_schedule : h->fast->default_schedule;
+      if (h->opt_schedule < 0 && (h->flags & PFB_FLAG_MAGNITUDE) && h->fast->magnitude_schedule >= 0 && !cm) {
+        p.schedule = h->fast->magnitude_schedule;  // fused abs(): magnitudes staged in LDS, sliding runs
+      }
       if (cm && !by_slabs)  // fused channel-major: 0 = sliding runs, 2 = tiles, 8 = short runs transposed in LDS, else the kernel's pick
         p.schedule = forced_fused ? h->opt_schedule : -1;
       if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;

@@ -89,6 +89,7 @@ struct FastKernelInfo {
   int cols_per_thread;     // CPT: vector-load alignment requirement
   int default_schedule;    // measured best schedule for this instantiation (PFB_OPT_SCHEDULE = -1)
   bool channel_major_ok;   // has a channel-major instantiation
+  int magnitude_schedule;  // measured best schedule with PFB_FLAG_MAGNITUDE, -1 = default_schedule
 };
 const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant = 0, bool channel_major = false);
 

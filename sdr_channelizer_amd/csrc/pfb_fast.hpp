@@ -360,6 +360,7 @@ struct FastKernel {
     constexpr bool LAST = (I == K::NP - 1);
     constexpr bool TW_REGS = (ITERS == 1) && !K::TW_TABLE;
     constexpr bool READ_BARRIER = !LAST && !K::PINGPONG && NT > 64;  // in place across several waves
+    constexpr bool kMagStaged = LAST && !CM && M == 64 && C == 8 && NT == 64 && ITERS == 1 && K::NP == 2 && !K::PINGPONG;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int w = tid + it * NT;
@@ -399,6 +400,34 @@ struct FastKernel {
           for (int k = 0; k < R; ++k) d2[k * KK * S1] = x[k];
         }
       } else {
+        if constexpr (kMagStaged) {
+          // fused abs() of the single-wave M = 64 kernels: a lane's 8 magnitudes are 8 channels apart, so storing them
+          // directly writes 32-byte pieces.  The chunk buffer is free once the wave has read it (the LDS executes a
+          // wave's accesses in order), so the magnitudes go there as rows of M floats (+8 pad: the 8 frames land on
+          // distinct banks) and leave as 16 bytes per lane: 4 frames x 256 contiguous bytes per instruction.
+          // (the sliding-run schedule only: there it is worth 7 %, 2.07 -> 1.93 ms per 2^30 samples, and makes sliding
+          // runs the fastest way to magnitudes; on the FFT wave of the pair schedules the extra LDS trip costs 2 %)
+          if ((p.flags & PFB_FLAG_MAGNITUDE) && p.schedule == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0) {
+            constexpr int SR = M + 8;
+            float* stage = reinterpret_cast<float*>(src);
+            const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
+            team_sync<true>();
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+              int col = kk + k * KK + shift;
+              col = col >= M ? col - M : col;
+              stage[fc * SR + col] = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
+            }
+            team_sync<true>();
+#pragma unroll
+            for (int j = 0; j < (C * M / 4) / 64; ++j) {
+              const int idx = tid + 64 * j, fr = idx / (M / 4), q = idx % (M / 4);
+              const float4 v = *reinterpret_cast<const float4*>(stage + fr * SR + q * 4);
+              if (f0 + fr < p.frames) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (f0 + fr) * M + q * 4) = v;
+            }
+            return;
+          }
+        }
         const long long f = f0 + fc;
         if (active && f < p.frames) {
           const bool flip_odd = (OS == 2) && (p.flags & PFB_FLAG_DEROTATE) && ((p.frame0 + f) & 1);
@@ -1630,6 +1659,11 @@ hipError_t init_tables(const float* taps, const float2* tw, float* taps_lane, fl
 // plans without a channel-major instantiation: it does not fit the register budget (the 1024-thread cfg4 plan
 // sits at its 128-VGPR ceiling already) or would be the shape's worst (chunks of 4 frames); channel-major
 // handles get the shape's next registered plan instead
+// fused abs() has a faster schedule than complex output on the shapes whose last pass can stage its magnitudes
+// in LDS (FastKernel::pass, kMagStaged): sliding runs
+template <class K>
+constexpr int kMagnitudeSchedule = (K::M == 64 && K::C == 8 && K::NT == 64 && K::NP == 2 && !K::PINGPONG) ? 0 : -1;
+
 template <class K>
 constexpr bool kChannelMajorOk = K::NT < 1024 && !(K::NP == 3 && K::C == 4);  // (C = 4 team plans: 32-byte runs)
 
