@@ -293,7 +293,8 @@ struct FastCfg {
 
 // CM = channel-major output, out[k * out_ld + out_frame0 + m] (MATLAB's column-major F x M): its own
 // instantiation, so the extra address arithmetic never costs the frame-major kernels a register.
-template <class K, bool CM = false>
+// MS = fused abs() with the magnitudes staged in LDS (its own instantiation of the sliding-run kernel, like CM)
+template <class K, bool CM = false, bool MS = false>
 struct FastKernel {
   static_assert(K::R(0) % 2 == 0 && (K::NP < 3 || K::R(1) % 2 == 0), "non-final radices are even (twiddle rows are read as float4s)");
   using ST = SampleT<K::FMT>;
@@ -360,7 +361,7 @@ struct FastKernel {
     constexpr bool LAST = (I == K::NP - 1);
     constexpr bool TW_REGS = (ITERS == 1) && !K::TW_TABLE;
     constexpr bool READ_BARRIER = !LAST && !K::PINGPONG && NT > 64;  // in place across several waves
-    constexpr bool kMagStaged = LAST && !CM && M == 64 && C == 8 && NT == 64 && ITERS == 1 && K::NP == 2 && !K::PINGPONG;
+    constexpr bool kMagStaged = MS && LAST;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int w = tid + it * NT;
@@ -405,10 +406,13 @@ struct FastKernel {
           // directly writes 32-byte pieces.  The chunk buffer is free once the wave has read it (the LDS executes a
           // wave's accesses in order), so the magnitudes go there as rows of M floats (+8 pad: the 8 frames land on
           // distinct banks) and leave as 16 bytes per lane: 4 frames x 256 contiguous bytes per instruction.
-          // (the sliding-run schedule only: there it is worth 7 %, 2.07 -> 1.93 ms per 2^30 samples, and makes sliding
-          // runs the fastest way to magnitudes; on the FFT wave of the pair schedules the extra LDS trip costs 2 %)
-          if ((p.flags & PFB_FLAG_MAGNITUDE) && p.schedule == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0) {
-            constexpr int SR = M + 8;
+          // (the sliding-run kernel only: there it is worth 7 %, 2.07 -> 1.93 ms per 2^30 samples, and makes sliding
+          // runs the fastest way to magnitudes; on the FFT wave of the pair schedules the extra LDS trip costs 2 %.
+          // launch_fast picks this instantiation when the flag is set and `out` is 16-byte aligned.)
+          static_assert(!CM && NT == 64 && ITERS == 1 && K::NP == 2 && !K::PINGPONG && M % 4 == 0, "single-wave two-pass plans");
+          {
+            constexpr int SR = M + ((8 - M % 64) + 64) % 64;  // = 8 (mod 64), a multiple of 4
+            static_assert(C * SR * sizeof(float) <= K::BUF * sizeof(float2), "the staged magnitudes fit the chunk buffer");
             float* stage = reinterpret_cast<float*>(src);
             const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
             team_sync<true>();
@@ -416,14 +420,17 @@ struct FastKernel {
             for (int k = 0; k < R; ++k) {
               int col = kk + k * KK + shift;
               col = col >= M ? col - M : col;
-              stage[fc * SR + col] = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
+              if (active) stage[fc * SR + col] = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
             }
             team_sync<true>();
+            constexpr int NV = C * M / 4;  // float4s in the chunk
 #pragma unroll
-            for (int j = 0; j < (C * M / 4) / 64; ++j) {
+            for (int j = 0; j < (NV + 63) / 64; ++j) {
               const int idx = tid + 64 * j, fr = idx / (M / 4), q = idx % (M / 4);
-              const float4 v = *reinterpret_cast<const float4*>(stage + fr * SR + q * 4);
-              if (f0 + fr < p.frames) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (f0 + fr) * M + q * 4) = v;
+              if ((NV % 64 == 0 || idx < NV) && f0 + fr < p.frames) {
+                const float4 v = *reinterpret_cast<const float4*>(stage + fr * SR + q * 4);
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (f0 + fr) * M + q * 4) = v;
+              }
             }
             return;
           }
@@ -1662,15 +1669,19 @@ hipError_t init_tables(const float* taps, const float2* tw, float* taps_lane, fl
 // fused abs() has a faster schedule than complex output on the shapes whose last pass can stage its magnitudes
 // in LDS (FastKernel::pass, kMagStaged): sliding runs
 template <class K>
-constexpr int kMagnitudeSchedule = (K::M == 64 && K::C == 8 && K::NT == 64 && K::NP == 2 && !K::PINGPONG) ? 0 : -1;
+constexpr bool kMagStagedOk = K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::M == 64 && K::C == 8;
+// (M = 64 only: there the direct stores are 32-byte pieces.  Measured elsewhere: cfg3, whose pieces are 64 bytes,
+// -3 %; M = 32 +-0; the M = 56 sliding kernel spilled with it)
+template <class K>
+constexpr int kMagnitudeSchedule = kMagStagedOk<K> ? (K::FMT == PFB_FMT_CF32 ? 7 : 0) : -1;  // (cf32: pairs still win)
 
 template <class K>
 constexpr bool kChannelMajorOk = K::NT < 1024 && !(K::NP == 3 && K::C == 4);  // (C = 4 team plans: 32-byte runs)
 
-template <class K, bool CM = false>
+template <class K, bool CM = false, bool MS = false>
 __global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_fast_kernel(const KernelParams p) {
   __shared__ float2 lds[K::LDS_ELEMS];
-  FastKernel<K, CM>::run(p, lds);
+  FastKernel<K, CM, MS>::run(p, lds);
 }
 
 template <class K>
@@ -1957,6 +1968,12 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
     if (p.schedule == 1) return launch_strided<K>(p, s);
   }
   const long long blocks = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
+  if constexpr (kMagStagedOk<K>) {
+    if ((p.flags & PFB_FLAG_MAGNITUDE) && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0) {
+      hipLaunchKernelGGL((pfb_fast_kernel<K, false, true>), dim3((unsigned)blocks), dim3(K::NT), 0, s, p);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL(pfb_fast_kernel<K>, dim3((unsigned)blocks), dim3(K::NT), 0, s, p);
   return hipGetLastError();
 }
