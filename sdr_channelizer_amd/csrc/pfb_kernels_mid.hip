@@ -25,16 +25,18 @@ using Cfg56x12i8  = FastCfg<56, 12, 56, 1, PFB_FMT_INT8_IQ,  8, 2, 8, 7, 1, 7, 9
 // M = 8 is 4 x 2, not 2 x 4: the last pass then leaves a lane group 4 adjacent channels (32-byte runs), worth 40 -> 56 %
 using Cfg32x12i16 = FastCfg<32, 12, 32, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 4, 1, 4, 9, 0, 36, false, 4>;
 using Cfg16x12i16 = FastCfg<16, 12, 16, 1, PFB_FMT_INT16_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, true, 4>;
-using Cfg8x12i16 = FastCfg<8, 12, 8, 1, PFB_FMT_INT16_IQ, 8, 2, 4, 2, 1, 2, 5, 0, 10, true, 4>;
+using Cfg8x12i16 = FastCfg<8, 12, 8, 1, PFB_FMT_INT16_IQ, 8, 2, 4, 2, 1, 2, 5, 0, 10, true, 3>;
+// (MIN_WAVES 3 for M = 8, 10 and the int8 M = 16: at 4 waves per SIMD these spilled 12-30 registers; without the spills
+// M = 8 56 -> 58 %, int8 35 -> 43 %, cf32 57 -> 66 %, M = 16 int8 32 -> 36 %, M = 10 38 -> 46 %)
 using Cfg32x12i8 = FastCfg<32, 12, 32, 1, PFB_FMT_INT8_IQ, 8, 2, 8, 4, 1, 4, 9, 0, 36, false, 4>;
-using Cfg16x12i8 = FastCfg<16, 12, 16, 1, PFB_FMT_INT8_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, true, 4>;
-using Cfg8x12i8 = FastCfg<8, 12, 8, 1, PFB_FMT_INT8_IQ, 8, 2, 4, 2, 1, 2, 5, 0, 10, true, 4>;
-using Cfg8x12f32 = FastCfg<8, 12, 8, 1, PFB_FMT_CF32, 8, 2, 4, 2, 1, 2, 5, 0, 10, true, 4>;
+using Cfg16x12i8 = FastCfg<16, 12, 16, 1, PFB_FMT_INT8_IQ, 8, 2, 4, 4, 1, 4, 5, 0, 20, true, 3>;
+using Cfg8x12i8 = FastCfg<8, 12, 8, 1, PFB_FMT_INT8_IQ, 8, 2, 4, 2, 1, 2, 5, 0, 10, true, 3>;
+using Cfg8x12f32 = FastCfg<8, 12, 8, 1, PFB_FMT_CF32, 8, 2, 4, 2, 1, 2, 5, 0, 10, true, 3>;
 // numBands at the bladeRF's round rates 10 / 20 / 40 Msps: 5 x 2, 10 x 2, 8 x 5 (5- and 10-point DFTs); 6, 3 and 1
 // segments per wave (60 / 60 / 40 of 64 lanes work).  M = 20 as 10 x 2, not 4 x 5: 80-byte instead of 32-byte store
 // runs, 36 -> 51 %; M = 10 as 5 x 2, not 2 x 5 (odd first radix: SegKernel reads those twiddle rows element by
 // element): 30 -> 39 %; M = 40 as 10 x 4 measured half the speed of 8 x 5
-using Cfg10x12i16 = FastCfg<10, 12, 10, 1, PFB_FMT_INT16_IQ, 8, 2, 5, 2, 1, 2, 5, 0, 10, true, 4>;
+using Cfg10x12i16 = FastCfg<10, 12, 10, 1, PFB_FMT_INT16_IQ, 8, 2, 5, 2, 1, 2, 5, 0, 10, true, 3>;
 using Cfg20x12i16 = FastCfg<20, 12, 20, 1, PFB_FMT_INT16_IQ, 8, 2, 10, 2, 1, 2, 15, 0, 42, true, 3>;
 using Cfg40x12i16 = FastCfg<40, 12, 40, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 5, 1, 5, 9, 0, 45, true, 4>;
 
