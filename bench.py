@@ -8,7 +8,8 @@ synthetic pulsed stream per GPU, already resident in HBM when the clock starts. 
 one pass of the channelizer over that batch.  At N>1 the stream is time-sharded: every rank
 owns one contiguous 2^30-sample segment (weak scaling) and, each step, hands the last
 history_samples() raw samples of its segment to the next rank over RCCL (the only
-data-path communication) before running its kernel.
+data-path communication; SURVEY.md section 8e: one all_gather of the tails by default,
+--halo p2p for neighbour send/recv) before running its kernel.
 
 Prints ONE JSON line on rank 0.
 """
@@ -92,6 +93,8 @@ def main() -> None:
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--halo", default="allgather", choices=("allgather", "p2p"),
+                    help="how the ring of halos moves: one all_gather of the tails, or send/recv between neighbours")
     args = ap.parse_args()
 
     import torch
@@ -99,7 +102,7 @@ def main() -> None:
 
     from sdr_channelizer_amd import Channelizer, design_prototype, synth
     from sdr_channelizer_amd import _lib as L
-    from sdr_channelizer_amd.sharded import exchange_halo
+    from sdr_channelizer_amd.sharded import exchange_halo, exchange_halo_allgather
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -149,7 +152,10 @@ def main() -> None:
         if world > 1:
             # time shard: my history is the tail of the previous rank's segment (ring, so rank 0
             # continues from the last rank's previous batch)
-            exchange_halo(iq[n - hist:], halo, rank, world)
+            if args.halo == "p2p":
+                exchange_halo(iq[n - hist:], halo, rank, world)
+            else:
+                exchange_halo_allgather(iq[n - hist:], halo, rank, world)
             ch.prime(halo)
         ch(iq, out=out, sync=False)
 

@@ -60,6 +60,26 @@ def exchange_halo(tail, halo_out, rank: int, world: int, group=None, ring: bool 
     return halo_out
 
 
+def exchange_halo_allgather(tail, halo_out, rank: int, world: int, group=None):
+    """The ring exchange as ONE collective: every rank contributes its tail, takes its predecessor's
+    (SURVEY.md section 8e's alternative: world x history_samples raw samples, a few KB).  Same result as
+    exchange_halo(ring=True); no point-to-point channels to set up."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return halo_out
+    on_host = dist.get_backend(group) == "gloo" and tail.is_cuda
+    snd = tail.contiguous().view(torch.uint8).reshape(-1)
+    if on_host:
+        snd = snd.cpu()
+    nb = snd.numel()
+    everyone = torch.empty(world * nb, dtype=torch.uint8, device=snd.device)  # flat: gloo takes no other shape
+    dist.all_gather_into_tensor(everyone, snd, group=group)
+    prv = (rank - 1) % world
+    halo_out.view(torch.uint8).reshape(-1).copy_(everyone[prv * nb:(prv + 1) * nb])
+    return halo_out
+
+
 class ShardedChannelizer:
     """One rank's view of a time-sharded channelizer run.
 

@@ -13,7 +13,8 @@ import torch.multiprocessing as mp
 
 from oracle.pfb_oracle import COracle, OracleConfig
 from sdr_channelizer_amd import synth
-from sdr_channelizer_amd.sharded import ShardedChannelizer, exchange_halo, records_for_rank, segment_bounds
+from sdr_channelizer_amd.sharded import (ShardedChannelizer, exchange_halo, exchange_halo_allgather, records_for_rank,
+                                         segment_bounds)
 
 M, P, D, BW = 16, 4, 8, 12
 
@@ -65,6 +66,9 @@ def _worker(rank, world, port, total, taps, ret):
         # ring variant used by bench.py: everyone receives, rank 0 from the last rank
         halo = torch.zeros((M * P + D, 2), dtype=torch.int16)
         exchange_halo(seg[-(M * P + D):].contiguous(), halo, rank, world, ring=True)
+        halo2 = torch.zeros((M * P + D, 2), dtype=torch.int16)   # the same ring as one all_gather
+        exchange_halo_allgather(seg[-(M * P + D):].contiguous(), halo2, rank, world)
+        assert torch.equal(halo2, halo)
         ret[rank] = (np.asarray(y), halo.numpy().copy(), seg.numpy()[-(M * P + D):].copy())
     finally:
         dist.destroy_process_group()
