@@ -93,6 +93,8 @@ def main() -> None:
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--channel-major", action="store_true",
+                    help="write MATLAB's column-major F x M matrix instead of frame-major rows (not the headline line)")
     ap.add_argument("--halo", default="allgather", choices=("allgather", "p2p"),
                     help="how the ring of halos moves: one all_gather of the tails, or send/recv between neighbours")
     args = ap.parse_args()
@@ -127,9 +129,10 @@ def main() -> None:
     # rank r owns stream samples [r*n, (r+1)*n): generate that slice of the pulse train in HBM
     iq = synth.pulsed_iq_torch(n, bw, tdtype, seed=synth.SEED + rank, device=dev)
     F = n // D + 1  # +1: with M not a power of two the carried tail completes an extra frame every few steps
-    out = torch.empty((F, M), dtype=torch.complex64, device=dev)
+    out = torch.empty((M, F) if args.channel_major else (F, M), dtype=torch.complex64, device=dev)
 
-    ch = Channelizer(M, taps=taps, decimation=D, sample_format=fmt, bit_width=bw, device=local_rank)
+    ch = Channelizer(M, taps=taps, decimation=D, sample_format=fmt, bit_width=bw, device=local_rank,
+                     channel_major=args.channel_major)
     stream = torch.cuda.current_stream(dev)
     ch.set_stream(stream.cuda_stream)
     ch.set_option(L.PFB_OPT_KERNEL, 2)  # the hand-written fast kernel or nothing
@@ -191,7 +194,7 @@ def main() -> None:
         achieved = n * bytes_per_sample / (k_ms * 1e-3) / 1e9  # algorithmic bytes per launch / avg launch time
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile) and args.workload == "cfg2" and args.log2_samples == 30:
+        if os.path.exists(tfile) and args.workload == "cfg2" and args.log2_samples == 30 and not args.channel_major:
             try:
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except Exception:
@@ -212,10 +215,11 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: M={M} channels, {P} taps/branch, D={D}, {fmt} I/Q "
-                                   f"({bw}-bit), 2^{args.log2_samples} samples per GPU per step, frame-major complex64 out",
+                                   f"({bw}-bit), 2^{args.log2_samples} samples per GPU per step, {'channel-major' if args.channel_major else 'frame-major'} complex64 out",
                        "kernel": ch.last_kernel,
                        "schedule": args.schedule if args.schedule >= 0 else
-                       ("default (4: FIR/FFT wave pairs, 8x64-frame workgroups)" if M == 64 else "default (0: sliding runs)"),
+                       ("default (channel-major route of the shape, DESIGN.md section 5.2)" if args.channel_major else
+                        "default (4: FIR/FFT wave pairs, 8x64-frame workgroups)" if M == 64 else "default (0: sliding runs)"),
                        "samples_per_gpu": n, "prewarm_steps": prewarm,
                        "parallelism": f"time-sharded x{world}, halo {hist} samples/rank over RCCL" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -505,6 +505,19 @@ struct FastKernel {
   // overwritten in place by the chunk TRANSPOSED, slot[column * C + frame] (fftshift and the derotation sign
   // applied), for run_tile_t's channel-major flush.  All of the wave's reads are issued before its first write
   // (the LDS executes one wave's accesses in order), so no second buffer is needed.
+  // Where frame fc of column col sits inside the column's C-frame group of a transposed slot.  The LDS serves a
+  // ds_write_b64 sixteen lanes at a time over 32 banks, i.e. over float2 addresses mod 16; the sixteen lanes of a
+  // last-pass store are min(16, M / R) adjacent columns x the rest in frames, and col * C + fc puts columns
+  // 16 / C apart on the same banks (rocprofv3: SQ_LDS_BANK_CONFLICT 0.19 cycles per sample, a 4-way conflict on
+  // every store).  XOR-ing the column's higher bits into the frame index gives the sixteen lanes sixteen different
+  // addresses mod 16; the flush reads whole groups per column, so the permutation inside a group costs it nothing
+  // (counter after: 0).
+  PFB_DEV int tslot_frame(int col, int fc) {
+    constexpr int IPF = M / K::R(K::NP - 1), NFC = IPF >= 16 ? 1 : 16 / IPF, Q = 16 / C;
+    static_assert(16 % C == 0 && (IPF >= 16 || 16 % IPF == 0) && C % NFC == 0, "power-of-two chunk and lane groups");
+    return fc ^ (NFC * ((col / Q) % (C / NFC)));
+  }
+
   PFB_DEV void last_pass_transposed(const KernelParams& p, float2* slot, int tid, long long f0) {
     constexpr int I = K::NP - 1;
     constexpr int R = K::R(I), KK = K::K(I), RS = K::RS(I);
@@ -537,7 +550,7 @@ struct FastKernel {
         for (int k = 0; k < R; ++k) {
           v2f v = x[it][k];
           if (flip_odd && ((kk + k * KK) & 1)) v = -v;
-          t2[col * C + fc] = v;
+          t2[col * C + tslot_frame(col, fc)] = v;
           col += KK;
           if (col >= M) col -= M;
         }
@@ -1419,7 +1432,7 @@ struct FastKernel {
 #pragma unroll
       for (int i = 0; i < IT / HALF; ++i) {
         const int e = (h * (IT / HALF) + i) * NTH + (int)threadIdx.x, col = e / RL, fr = e % RL;
-        v[i] = t2[(fr / C) * TSLOT + col * C + fr % C];
+        v[i] = t2[(fr / C) * TSLOT + col * C + tslot_frame(col, fr % C)];
       }
 #pragma unroll
       for (int i = 0; i < IT / HALF; ++i) {
