@@ -10,10 +10,12 @@ namespace pfb {
 // no single frame stride serves both passes, tools/fft_plan_model.py); schedule 7 (6 FIR/FFT wave pairs per
 // workgroup) measured within noise of one wave doing both (+0..3 %), so the default stays schedule 0
 using Cfg128x12os2i16 = FastCfg<128, 12, 64, 1, PFB_FMT_INT16_IQ, 8, 2, 16, 8, 1, 8, 17, 0, 136, false, 2>;
-// cfg3: 4 adjacent columns per lane (8-byte loads of int8 I/Q), 256 = 16 x 16, conflict-free; short sliding runs (32
+// cfg3: 4 adjacent columns per lane (8-byte loads of int8 I/Q), 256 = 16 x 16, rows of both passes padded to 17
+// (RS0 = 16 made every FIR write a 4-way LDS conflict: lanes 4 elements apart, sixteen lanes per LDS cycle over
+// float2 addresses mod 16; SQ_LDS_BANK_CONFLICT 43 % of the LDS cycles -> 0); short sliding runs (32
 // frames, 22 % more row reads of a stream that is 80 % writes) keep the chip's active window small: +4 % over 256
-using Cfg256x8i8  = FastCfg<256, 8, 256, 4, PFB_FMT_INT8_IQ,  4, 2, 16, 16, 1, 16, 17, 0, 272, false, 2>;
-using Cfg256x8i16 = FastCfg<256, 8, 256, 4, PFB_FMT_INT16_IQ, 4, 2, 16, 16, 1, 16, 17, 0, 272, false, 2>;
+using Cfg256x8i8  = FastCfg<256, 8, 256, 4, PFB_FMT_INT8_IQ,  4, 2, 16, 16, 1, 17, 17, 0, 272, false, 2>;
+using Cfg256x8i16 = FastCfg<256, 8, 256, 4, PFB_FMT_INT16_IQ, 4, 2, 16, 16, 1, 17, 17, 0, 272, false, 2>;
 // the reference's own band count: numBands = fs*1e-6 = 56 (channelizer_example.m:29, generate_pulsed_iq.m:12),
 // 56 = 8 x 7; 56 of the wave's 64 lanes own columns (2-way LDS conflicts on about half the accesses); default
 // schedule 7 (8 FIR/FFT wave pairs per workgroup over sliding runs of 512 frames, +17 %)

@@ -107,7 +107,7 @@ PLANS = {
     # name: (M, R, RS, FS, C, NT)
     "m64": (64, [8, 8], [8, 9], 72, 8, 64),
     "m128": (128, [16, 8], [8, 17], 136, 8, 64),     # final-pass reads 2-way
-    "m256": (256, [16, 16], [16, 17], 272, 4, 64),
+    "m256": (256, [16, 16], [17, 17], 272, 4, 64),
     "m1024": (1024, [16, 16, 4], [64, 68, 260], 1088, 8, 512),   # 8-wave lockstep plan and (C = 4) the team plan
     "m1024_16w": (1024, [8, 8, 16], [128, 128, 65], 1040, 8, 1024),
     "m56": (56, [8, 7], [7, 9], 71, 8, 64),           # the reference's fs*1e-6; 2-way on ~half the accesses
