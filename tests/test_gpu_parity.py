@@ -197,6 +197,23 @@ def test_channel_major_routes_are_bit_identical(M, P, D, fmt, bw, routes):
                 assert torch.equal(torch.cat([q for q in parts if q.numel()], dim=1), want), (M, mag, sched, arg)
 
 
+@pytest.mark.parametrize("M,P,log2n", [(64, 12, 28), (1024, 16, 28), (560, 12, 27)])
+def test_channel_major_at_size_equals_frame_major(M, P, log2n):
+    """The default channel-major route at BASELINE-like sizes (millions of frames: thousands of transposed tiles, or
+    several default-length slabs for the team plans) against the frame-major result, bit for bit, column by column."""
+    import torch
+    n = (1 << log2n) + 3 * M + 5
+    iq = synth.pulsed_iq_torch(n, 12, device="cuda")
+    h = np.random.default_rng(8).standard_normal(M * P).astype(np.float32) / M
+    with Channelizer(M, taps=h, bit_width=12, fftshift=True) as a, \
+            Channelizer(M, taps=h, bit_width=12, fftshift=True, channel_major=True) as b:
+        fm = a(iq)
+        cm = b(iq)
+        assert cm.shape == (M, n // M) and fm.shape == (n // M, M)
+        for c0 in range(0, M, 64):   # compare in column blocks: no third full-size buffer
+            assert torch.equal(cm[c0:c0 + 64], fm[:, c0:c0 + 64].T), (M, c0)
+
+
 @pytest.mark.parametrize("M,P,D,fmt,bw", [(64, 12, 64, "int16", 12), (128, 12, 64, "int16", 12), (56, 12, 56, "int16", 12),
                                           (256, 8, 256, "int8", 8), (560, 12, 560, "int16", 12), (16, 12, 16, "int16", 12),
                                           (20, 12, 20, "int16", 12), (40, 12, 40, "int16", 12)])
