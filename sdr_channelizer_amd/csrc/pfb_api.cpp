@@ -218,6 +218,7 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
         long long sf = h->opt_slab_frames > 0 ? h->opt_slab_frames : (long long)h->num_cus * fpb;  // one run per CU
         sf = std::max<long long>(64, (sf + 63) / 64 * 64);
         sf = std::max<long long>(sf, (h->hist_samples + h->D - 1) / h->D + 1);  // a later slab's window reaches back into the input, never into the history
+        sf = std::min<long long>(sf, 65535ll * 64);  // the transpose kernel's grid: one row of 64 x 64 tiles per 64 frames
         sf = std::min<long long>(sf, ((long long)frames + 63) / 64 * 64);
         const size_t need = (size_t)sf * h->M * h->out_elem;
         if (need > h->slab_bytes) {
