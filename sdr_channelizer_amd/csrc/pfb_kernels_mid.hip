@@ -42,6 +42,11 @@ using Cfg10x12i16 = FastCfg<10, 12, 10, 1, PFB_FMT_INT16_IQ, 8, 2, 5, 2, 1, 2, 5
 using Cfg20x12i16 = FastCfg<20, 12, 20, 1, PFB_FMT_INT16_IQ, 8, 2, 10, 2, 1, 2, 15, 0, 42, true, 3>;
 using Cfg40x12i16 = FastCfg<40, 12, 40, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 5, 1, 5, 9, 0, 45, true, 4>;
 
+// M = 32 with 8-bit samples: in the ordinary kernel half the lanes of every 2-byte row load are idle, and sub-dword
+// loads cost the memory pipeline as much as full ones -- 25 % of roofline.  Two segments per wave (SegKernel) fill
+// the loads: 47 % (with 4-byte samples the ordinary kernel stays ahead, 54 vs 51 %)
+using Cfg32x12i8seg = FastCfg<32, 12, 32, 1, PFB_FMT_INT8_IQ, 8, 2, 8, 4, 1, 4, 9, 0, 36, true, 3>;
+
 static const FastEntry kRows[] = {
     entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 512, 0),
     entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 32, 0),
@@ -49,7 +54,8 @@ static const FastEntry kRows[] = {
     entry<Cfg32x12i16>("pfb_fast<M32,P12,D32,int16>", 512, 0),
     seg_entry<Cfg16x12i16>("pfb_fast<M16,P12,D16,int16>", 1024),
     seg_entry<Cfg8x12i16>("pfb_fast<M8,P12,D8,int16>", 1024),
-    entry<Cfg32x12i8>("pfb_fast<M32,P12,D32,int8>", 512, 0),
+    seg_entry<Cfg32x12i8seg>("pfb_fast<M32,P12,D32,int8>", 1024),
+    entry<Cfg32x12i8>("pfb_fast<M32,P12,D32,int8,1seg>", 512, 0),
     seg_entry<Cfg16x12i8>("pfb_fast<M16,P12,D16,int8>", 1024),
     seg_entry<Cfg8x12i8>("pfb_fast<M8,P12,D8,int8>", 1024),
     seg_entry<Cfg8x12f32>("pfb_fast<M8,P12,D8,cf32>", 1024),
