@@ -355,31 +355,52 @@ struct FastKernel {
 
   // The C rows of a chunk.  2-byte samples, one column per lane, rows that are not whole cache lines (M = 56 int8:
   // 112-byte rows, 21 % of roofline with one 2-byte load per row): pairs of rows are fetched as ONE dword load --
-  // lanes [0, D/2) take row r (two columns each), lanes [D/2, D) row r + 1 -- and two ds_bpermutes hand every lane
-  // its own column of both rows: 21 -> 26 %.  (With 128-byte rows, M = 64 int8, it measured 3 % slower and is off.)
-  // Needs the run's rows on a 4-byte boundary (uniform check).
+  // lanes [0, D/2) take row r (two columns each), lanes [D/2, D) row r + 1 -- and, when the chunk is consumed, two
+  // ds_bpermutes hand every lane its own column of both rows.  load_rows only issues the loads (they stay in flight
+  // under the previous chunk's arithmetic like the ordinary row loads); finish_rows does the exchange.  (With
+  // 128-byte rows, M = 64 int8, pairing measured +2 % complex, -10 % with fused abs(): off.)  Needs the run's rows on a 4-byte boundary.
+  static constexpr bool kPairedRows = sizeof(raw_t) == 2 && CPT == 1 && C % 2 == 0 && D % 2 == 0 && D < 64 && NT == 64;
+  struct RowFetch {
+    uint32_t pw[C / 2 > 0 ? C / 2 : 1];
+    bool paired;
+  };
+
+  template <bool INTERIOR>
+  PFB_DEV void begin_rows(const raw_t* run_ptr, RowFetch& rf) {
+    rf.paired = kPairedRows && INTERIOR && (reinterpret_cast<uintptr_t>(run_ptr) & 3) == 0;
+  }
+
   template <bool INTERIOR>
   PFB_DEV void load_rows(const KernelParams& p, const raw_t* run_ptr, long long f_first, long long rel_first, int c0,
-                         raw_t (&raw)[C][CPT]) {
-    if constexpr (INTERIOR && sizeof(raw_t) == 2 && CPT == 1 && C % 2 == 0 && D % 2 == 0 && D < 64 && NT == 64) {
-      if ((reinterpret_cast<uintptr_t>(run_ptr) & 3) == 0) {
-        constexpr int HALF = D / 2;  // dwords per row
+                         raw_t (&raw)[C][CPT], RowFetch& rf) {
+    if constexpr (kPairedRows && INTERIOR) {
+      if (rf.paired) {
         const int lane = threadIdx.x & 63;
-        const int src = (c0 < D ? c0 : 0) >> 1, sh = (c0 & 1) * 16;
 #pragma unroll
         for (int t = 0; t < C; t += 2) {
           const uint32_t* rp = reinterpret_cast<const uint32_t*>(run_ptr + (rel_first + t) * D);
-          const uint32_t w = lane < 2 * HALF ? rp[lane] : 0u;
-          const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(src * 4, (int)w);
-          const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((HALF + src) * 4, (int)w);
-          raw[t][0] = c0 < D ? (raw_t)((a >> sh) & 0xffffu) : raw_t{};
-          raw[t + 1][0] = c0 < D ? (raw_t)((b >> sh) & 0xffffu) : raw_t{};
+          rf.pw[t / 2] = lane < D ? rp[lane] : 0u;
         }
         return;
       }
     }
 #pragma unroll
     for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_first + t, rel_first + t, c0, raw[t]);
+  }
+
+  PFB_DEV void finish_rows(int c0, raw_t (&raw)[C][CPT], const RowFetch& rf) {
+    if constexpr (kPairedRows) {
+      if (rf.paired) {
+        const int src = (c0 < D ? c0 : 0) >> 1, sh = (c0 & 1) * 16;
+#pragma unroll
+        for (int t = 0; t < C; t += 2) {
+          const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(src * 4, (int)rf.pw[t / 2]);
+          const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((D / 2 + src) * 4, (int)rf.pw[t / 2]);
+          raw[t][0] = c0 < D ? (raw_t)((a >> sh) & 0xffffu) : raw_t{};
+          raw[t + 1][0] = c0 < D ? (raw_t)((b >> sh) & 0xffffu) : raw_t{};
+        }
+      }
+    }
   }
 
   template <int I>
@@ -736,16 +757,19 @@ struct FastKernel {
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(t[cc]);
     }
-    load_rows<INTERIOR>(p, run_ptr, f_begin, W - 1, c0, raw);
+    RowFetch rf;
+    begin_rows<INTERIOR>(run_ptr, rf);
+    load_rows<INTERIOR>(p, run_ptr, f_begin, W - 1, c0, raw, rf);
 
     for (long long f0 = f_begin; f0 < f_end; f0 += C) {
+      finish_rows(c0, raw, rf);
 #pragma unroll
       for (int t = 0; t < C; ++t)
 #pragma unroll
         for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);
       if (f0 + C < f_end) {  // prefetch the next chunk's rows under this chunk's FFT
         const long long rel = (f0 - f_begin) + C + (W - 1);
-        load_rows<INTERIOR>(p, run_ptr, f0 + C, rel, c0, raw);
+        load_rows<INTERIOR>(p, run_ptr, f0 + C, rel, c0, raw, rf);
       }
       fir_fft_store(p, k, x, lds, tid, f0);
       // slide the window by C rows
@@ -1132,18 +1156,21 @@ struct FastKernel {
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(t[cc]);
     }
-    load_rows<INTERIOR>(p, run_ptr, f_begin, W - 1, c0, raw);
+    RowFetch rf;
+    begin_rows<INTERIOR>(run_ptr, rf);
+    load_rows<INTERIOR>(p, run_ptr, f_begin, W - 1, c0, raw, rf);
     for (int ci2 = 0; ci2 < nch; ci2 += 2) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int ci = ci2 + u;
+        finish_rows(c0, raw, rf);
 #pragma unroll
         for (int t = 0; t < C; ++t)
 #pragma unroll
           for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);
         if (ci + 1 < nch) {
           const long long rel = (long long)(ci + 1) * C + (W - 1);
-          load_rows<INTERIOR>(p, run_ptr, f_begin + (long long)(ci + 1) * C, rel, c0, raw);
+          load_rows<INTERIOR>(p, run_ptr, f_begin + (long long)(ci + 1) * C, rel, c0, raw, rf);
         }
         fir_to_lds(k, x, bufs + u * K::BUF, tid);
 #pragma unroll
@@ -1402,14 +1429,17 @@ struct FastKernel {
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(t[cc]);
     }
-    load_rows<INTERIOR>(p, run_ptr, f_begin, W - 1, c0, raw);
+    RowFetch rf;
+    begin_rows<INTERIOR>(run_ptr, rf);
+    load_rows<INTERIOR>(p, run_ptr, f_begin, W - 1, c0, raw, rf);
 #pragma unroll
     for (int ci = 0; ci < CPW; ++ci) {
+      finish_rows(c0, raw, rf);
 #pragma unroll
       for (int t = 0; t < C; ++t)
 #pragma unroll
         for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);
-      if (ci + 1 < CPW) load_rows<INTERIOR>(p, run_ptr, f_begin + (ci + 1) * C, W - 1 + (ci + 1) * C, c0, raw);
+      if (ci + 1 < CPW) load_rows<INTERIOR>(p, run_ptr, f_begin + (ci + 1) * C, W - 1 + (ci + 1) * C, c0, raw, rf);
       fir_fft_store<true, true>(p, k, x, slots + ci * TSLOT, tid, f_begin + ci * C);
       if (ci + 1 < CPW) {
 #pragma unroll

@@ -63,7 +63,7 @@ static const FastEntry kRows[] = {
     seg_entry<Cfg20x12i16>("pfb_fast<M20,P12,D20,int16>", 1008),
     seg_entry<Cfg40x12i16>("pfb_fast<M40,P12,D40,int16>", 1024),
     entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 7),
-    entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 128, 0),  // 2-byte 112-byte rows: sliding runs of 128 with paired row loads (36 %; pairs 21-26 %)
+    entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 7),
 };
 
 FastTablePart fast_table_mid() { return FastTablePart{kRows, (int)(sizeof(kRows) / sizeof(kRows[0]))}; }
