@@ -5,24 +5,28 @@ channelizer kernel against the MI355X roofline (BASELINE.json metric).
 Workload (configs[1], the one the metric is quoted on): M=64 channels, 12 taps/branch,
 D=64, int16 I/Q in the blade_record_iq_12bit format (12-bit in int16), a 2^30-sample
 synthetic pulsed stream per GPU, already resident in HBM when the clock starts.  A "step" is
-one pass of the channelizer over that batch.  At N>1 the stream is time-sharded: every rank
-owns one contiguous 2^30-sample segment (weak scaling) and, each step, hands the last
-history_samples() raw samples of its segment to the next rank over RCCL (the only
-data-path communication; SURVEY.md section 8e: one all_gather of the tails by default,
---halo p2p for neighbour send/recv) before running its kernel.
+one pass of the channelizer over that batch.
 
-Prints ONE JSON line on rank 0.
+N > 1: the stream is time-sharded.  Rank r owns samples [r*n, (r+1)*n) of ONE
+counter-based stream (same seed everywhere) and every step runs pfb_process_shard_async: the last
+(P-1)*M raw samples of its segment go to rank r+1 over RCCL on a side stream while the frames that do
+not touch the halo run at once; the first frames follow when the halo has landed.  Weak scaling, no
+other communication.  `python bench.py --gpus N` starts its own N ranks (fresh child processes, before
+this process touches torch or the GPU); under torch.distributed.run it runs as the rank it is given.
+
+Prints ONE JSON line on rank 0.  At N = 1 the line also carries short timed passes of the other
+BASELINE configurations (`other_workloads`), a >= 2 s sustained window (`roofline.sustained_frac`) and
+the CPU baseline (the oracle's naive fp32 port, all host threads and one thread).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -30,52 +34,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 WORKLOADS = {
-    # name: (M, P, D, fmt, bit_width, bytes_in_per_sample)
-    "cfg2": (64, 12, 64, "int16", 12, 4),
-    "cfg3": (256, 8, 256, "int8", 8, 2),
-    "cfg4": (1024, 16, 1024, "int16", 16, 4),
-    "cfg5": (128, 12, 64, "int16", 12, 4),
-    "ref56": (56, 12, 56, "int16", 12, 4),     # the reference's own band counts at fs = 56 MHz
-    "ref560": (560, 12, 560, "int16", 12, 4),
+    # name: (M, P, D, fmt, bit_width, bytes_in_per_sample, log2 samples of the BASELINE.json configuration)
+    "cfg2": (64, 12, 64, "int16", 12, 4, 30),
+    "cfg3": (256, 8, 256, "int8", 8, 2, 30),
+    "cfg4": (1024, 16, 1024, "int16", 16, 4, 30),
+    "cfg5": (128, 12, 64, "int16", 12, 4, 28),
+    "ref56": (56, 12, 56, "int16", 12, 4, 28),     # the reference's own band counts at fs = 56 MHz
+    "ref560": (560, 12, 560, "int16", 12, 4, 28),
 }
+# what the default N = 1 run times after the headline: (workload, channel_major)
+OTHER_WORKLOADS = [("cfg3", False), ("cfg4", False), ("cfg5", False), ("ref56", False), ("ref560", False),
+                   ("cfg2", True), ("cfg3", True), ("cfg4", True), ("cfg5", True)]
+TRAFFIC_SOURCE = "profiles/r02_pmc_traffic.json"  # rocprofv3 --pmc passes of this command (never measured in-run)
 
 
-def cpu_baseline(iq_prefix: np.ndarray, taps: np.ndarray, M: int, P: int, D: int, bw: int, budget_s: float):
-    """Time the oracle's fp32 OpenMP port (kind="port": no MATLAB exists for the reference's
-    dsp.Channelizer call) on a bounded prefix of the same stream, on this box's host cores."""
-    from oracle.pfb_oracle import COracle
-    src = os.path.join(ROOT, "oracle", "pfb_oracle.c")
-    path = None
-    try:  # tune for this host; fall back to the prebuilt portable build
-        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"libpfb_oracle_native_{os.getpid()}.so")
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-shared", "-o", out, src, "-lm"],
-                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        path = out
-    except Exception:
-        path = None
-    o = COracle(path)
-    cores = o.max_threads()
-    probe = iq_prefix[: 1 << 22]
-    o.channelize_f32_i16(probe, bw, taps, M, P, D, threads=cores)  # warm the thread pool and the caches
-    t0 = time.perf_counter()
-    o.channelize_f32_i16(probe, bw, taps, M, P, D, threads=cores)
-    rate = probe.shape[0] / (time.perf_counter() - t0)
-    # bounded sample: about budget_s core-seconds per core, never more than the prefix we were handed
-    n = int(min(iq_prefix.shape[0], max(1 << 22, rate * budget_s / 8)))
-    n -= n % D
-    reps, dt = 0, 0.0
-    while dt < 1.0 and reps < 8:  # at least ~1 s of wall time so the number is stable
-        t0 = time.perf_counter()
-        o.channelize_f32_i16(iq_prefix[:n], bw, taps, M, P, D, threads=cores)
-        dt += time.perf_counter() - t0
-        reps += 1
-    return {"value": round(reps * n / dt / 1e6, 3), "unit": "MS/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} samples of the same synthetic stream x{reps} passes, fp32 OpenMP polyphase+FFT "
-                      f"port of the oracle (oracle/pfb_oracle.c, built -O3 -march=native on this host), "
-                      f"{dt:.2f} s wall = {dt * cores:.0f} core-seconds"}
-
-
-def main() -> None:
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: the first ~15 launches after an idle GPU run 3-25 % slow (clock ramp, tools/launch_series.py),
@@ -90,28 +63,122 @@ def main() -> None:
     ap.add_argument("--schedule", type=int, default=-1)
     ap.add_argument("--grid", type=int, default=-1)
     ap.add_argument("--tile-waves", type=int, default=-1)
+    ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the other BASELINE configurations")
+    ap.add_argument("--sustained-s", type=float, default=2.2, help="length of the sustained window (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--channel-major", action="store_true",
                     help="write MATLAB's column-major F x M matrix instead of frame-major rows (not the headline line)")
-    ap.add_argument("--halo", default="allgather", choices=("allgather", "p2p"),
-                    help="how the ring of halos moves: one all_gather of the tails, or send/recv between neighbours")
-    args = ap.parse_args()
+    ap.add_argument("--halo", default="p2p", choices=("p2p", "allgather"),
+                    help="how the halos move: send/recv between neighbours (ncclSend/ncclRecv), or one all_gather of the tails")
+    return ap.parse_args()
 
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start N fresh rank processes.  Nothing in THIS process
+    has imported torch or touched the GPU, and no child re-execs: each is a new interpreter that finds RANK / WORLD_SIZE
+    in its environment.  Rank 0's stdout (the JSON line) passes through; any child failing fails the run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(args.gpus))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [None] * len(procs)
+    try:
+        while any(c is None for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.poll()
+            if any(c not in (None, 0) for c in codes):  # one rank died: the others would wait in a collective forever
+                break
+            time.sleep(0.2)
+    finally:
+        for i, p in enumerate(procs):  # exactly the PIDs started above
+            if codes[i] is None and p.poll() is None:
+                p.terminate()
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+                codes[i] = p.returncode if p.returncode is not None else 1
+    bad = [(i, c) for i, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def cpu_baseline(iq_prefix, taps, M: int, P: int, D: int, bw: int, budget_s: float):
+    """Time the oracle's fp32 OpenMP port (kind="port": no MATLAB exists for the reference's
+    dsp.Channelizer call) on a bounded prefix of the same stream, on this box's host cores: all hardware
+    threads and one thread (BASELINE.md's plan).  The port is NAIVE -- scalar, one branch per tap, stride-M
+    gathers -- a baseline for orientation, not a tuned CPU channelizer."""
+    from oracle.pfb_oracle import COracle
+    src = os.path.join(ROOT, "oracle", "pfb_oracle.c")
+    path = None
+    try:  # tune for this host; fall back to the prebuilt portable build
+        out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"libpfb_oracle_native_{os.getpid()}.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-shared", "-o", out, src, "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        path = out
+    except Exception:
+        path = None
+    o = COracle(path)
+    cores = o.max_threads()
+
+    def timed(threads: int, budget: float):
+        probe = iq_prefix[: 1 << (22 if threads > 1 else 20)]
+        o.channelize_f32_i16(probe, bw, taps, M, P, D, threads=threads)  # warm the thread pool and the caches
+        t0 = time.perf_counter()
+        o.channelize_f32_i16(probe, bw, taps, M, P, D, threads=threads)
+        rate = probe.shape[0] / (time.perf_counter() - t0)
+        # bounded sample: about `budget` seconds of wall time, never more than the prefix we were handed
+        n = int(min(iq_prefix.shape[0], max(probe.shape[0], rate * budget)))
+        n -= n % D
+        reps, dt = 0, 0.0
+        while dt < min(1.0, budget) and reps < 8:  # at least ~1 s of wall time so the number is stable
+            t0 = time.perf_counter()
+            o.channelize_f32_i16(iq_prefix[:n], bw, taps, M, P, D, threads=threads)
+            dt += time.perf_counter() - t0
+            reps += 1
+        return round(reps * n / dt / 1e6, 3), n, reps, dt
+
+    v_all, n_all, r_all, dt_all = timed(cores, budget_s / 8)
+    v_one, n_one, r_one, dt_one = timed(1, min(4.0, budget_s / 3))
+    return {"value": v_all, "unit": "MS/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_all} samples of the same synthetic stream x{r_all} passes, NAIVE fp32 OpenMP polyphase+FFT "
+                      f"port of the oracle (oracle/pfb_oracle.c: scalar, branch per tap, stride-M gathers; built -O3 "
+                      f"-march=native on this host), {dt_all:.2f} s wall = {dt_all * cores:.0f} core-seconds",
+            "one_thread": {"value": v_one, "unit": "MS/s", "cores": 1,
+                           "sample": f"first {n_one} samples x{r_one} passes of the same port on one thread, {dt_one:.2f} s"}}
+
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))  # nothing above imported torch or touched the GPU
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     from sdr_channelizer_amd import Channelizer, design_prototype, synth
     from sdr_channelizer_amd import _lib as L
-    from sdr_channelizer_amd.sharded import exchange_halo, exchange_halo_allgather
+    from sdr_channelizer_amd.sharded import make_exchange
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if os.environ.get("PFB_BENCH_ONE_DEVICE"):  # rehearsal on a 1-GPU box: every rank shares device 0
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("PFB_BENCH_ONE_DEVICE"):  # rehearsal on a 1-GPU box: every rank shares device 0 (gloo only)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -122,45 +189,65 @@ def main() -> None:
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    M, P, D, fmt, bw, bytes_in = WORKLOADS[args.workload]
-    n = 1 << args.log2_samples
-    taps = design_prototype(M, P, 80.0)
-    tdtype = torch.int8 if fmt == "int8" else torch.int16
-    # rank r owns stream samples [r*n, (r+1)*n): generate that slice of the pulse train in HBM
-    iq = synth.pulsed_iq_torch(n, bw, tdtype, seed=synth.SEED + rank, device=dev)
-    F = n // D + 1  # +1: with M not a power of two the carried tail completes an extra frame every few steps
-    out = torch.empty((M, F) if args.channel_major else (F, M), dtype=torch.complex64, device=dev)
+    def make_handle(name: str, channel_major: bool, tuned: bool):
+        M, P, D, fmt, bw, _bytes_in, _ = WORKLOADS[name]
+        taps = design_prototype(M, P, 80.0)
+        ch = Channelizer(M, taps=taps, decimation=D, sample_format=fmt, bit_width=bw, device=local_rank,
+                         channel_major=channel_major)
+        ch.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ch.set_option(L.PFB_OPT_KERNEL, 2)  # the hand-written fast kernel or nothing
+        if tuned:  # command-line tuning knobs apply to the headline handle only
+            if args.variant >= 0:
+                ch.set_option(L.PFB_OPT_VARIANT, args.variant)
+            if args.frames_per_block:
+                ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, args.frames_per_block)
+            if args.nontemporal >= 0:
+                ch.set_option(L.PFB_OPT_NONTEMPORAL, args.nontemporal)
+            if args.xcd_remap >= -1:
+                ch.set_option(L.PFB_OPT_XCD_REMAP, args.xcd_remap)
+            if args.schedule >= 0:
+                ch.set_option(L.PFB_OPT_SCHEDULE, args.schedule)
+            if args.grid >= 0:
+                ch.set_option(L.PFB_OPT_GRID, args.grid)
+            if args.tile_waves >= 0:
+                ch.set_option(L.PFB_OPT_TILE_WAVES, args.tile_waves)
+        return ch, taps
 
-    ch = Channelizer(M, taps=taps, decimation=D, sample_format=fmt, bit_width=bw, device=local_rank,
-                     channel_major=args.channel_major)
-    stream = torch.cuda.current_stream(dev)
-    ch.set_stream(stream.cuda_stream)
-    ch.set_option(L.PFB_OPT_KERNEL, 2)  # the hand-written fast kernel or nothing
-    if args.frames_per_block:
-        ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, args.frames_per_block)
-    if args.nontemporal >= 0:
-        ch.set_option(L.PFB_OPT_NONTEMPORAL, args.nontemporal)
-    if args.xcd_remap >= -1:
-        ch.set_option(L.PFB_OPT_XCD_REMAP, args.xcd_remap)
-    if args.schedule >= 0:
-        ch.set_option(L.PFB_OPT_SCHEDULE, args.schedule)
-    if args.grid >= 0:
-        ch.set_option(L.PFB_OPT_GRID, args.grid)
-    if args.tile_waves >= 0:
-        ch.set_option(L.PFB_OPT_TILE_WAVES, args.tile_waves)
-    hist = ch.history_samples
-    halo = torch.zeros((hist, 2), dtype=tdtype, device=dev)
+    def make_buffers(name: str, log2n: int, channel_major: bool, start: int = 0):
+        M, P, D, fmt, bw, _bytes_in, _ = WORKLOADS[name]
+        n = 1 << log2n
+        tdtype = torch.int8 if fmt == "int8" else torch.int16
+        iq = synth.pulsed_iq_torch(n, bw, tdtype, seed=synth.SEED, device=dev, start=start)
+        F = n // D + 1  # +1: with M not a power of two the carried tail completes an extra frame every few steps
+        out = torch.empty((M, F) if channel_major else (F, M), dtype=torch.complex64, device=dev)
+        return iq, out
+
+    def kernel_ms_per_step(ch, launches_per_step: int):
+        t = ch.kernel_times_ms()
+        k = launches_per_step
+        return [sum(t[i:i + k]) for i in range(0, len(t) - len(t) % k, k)]
+
+    M, P, D, fmt, bw, bytes_in, _ = WORKLOADS[args.workload]
+    n = 1 << args.log2_samples
+    ch, taps = make_handle(args.workload, args.channel_major, tuned=True)
+    # ONE stream for the whole job: rank r owns samples [r*n, (r+1)*n) of it (counter-based generator, same seed)
+    iq, out = make_buffers(args.workload, args.log2_samples, args.channel_major, start=rank * n)
+    halo = ch.halo_samples
+    launches_per_step = 1
+    if world > 1:
+        if n % D:
+            raise SystemExit("time shards are cut on frame boundaries")
+        # ring: rank 0 continues from the last rank's tail of the previous step, so step after step is one endless stream
+        ch.attach_shard(rank, world, make_exchange(rank, world, None, args.halo, local_rank), ring=True)
+        launches_per_step = 2  # interior frames, then the head frames behind the halo event
+        F_shard = n // D
+        out = out.reshape(-1)[: F_shard * M].reshape((M, F_shard) if args.channel_major else (F_shard, M))
 
     def step():
         if world > 1:
-            # time shard: my history is the tail of the previous rank's segment (ring, so rank 0
-            # continues from the last rank's previous batch)
-            if args.halo == "p2p":
-                exchange_halo(iq[n - hist:], halo, rank, world)
-            else:
-                exchange_halo_allgather(iq[n - hist:], halo, rank, world)
-            ch.prime(halo)
-        ch(iq, out=out, sync=False)
+            ch.process_shard(iq, out=out)  # exchange on the side stream, interior frames now, head frames after the halo
+        else:
+            ch(iq, out=out, sync=False)
 
     # The first ~15 launches after an idle GPU run 3-25 % slow (clock ramp).  If the caller asks
     # for fewer warm-up steps than that, run the difference as extra untimed steps first; the W warm-up steps and the
@@ -168,6 +255,7 @@ def main() -> None:
     prewarm = max(0, 25 - args.warmup)
     for _ in range(prewarm + args.warmup):
         step()
+    ch.sync()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -176,14 +264,17 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    ch.sync()  # the handle's stream: kernels and, behind the halo event, the transfers
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ch.kernel_times_ms()
+    kernel_ms = kernel_ms_per_step(ch, launches_per_step)
     ch.set_option(L.PFB_OPT_PROFILE, 0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if args.backend != "nccl":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -192,15 +283,7 @@ def main() -> None:
         bytes_per_sample = bytes_in + 8 * (M // D)            # B = bytes_in + 8*(M/D)
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = n * bytes_per_sample / (k_ms * 1e-3) / 1e9  # algorithmic bytes per launch / avg launch time
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile) and args.workload == "cfg2" and args.log2_samples == 30 and not args.channel_major:
-            try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        copy_bps = L.C.c_double()
-        copy_rc = L.load().pfb_measure_stream_copy(local_rank, 1 << 30, 5, L.C.byref(copy_bps))
+        headline_kernel = ch.last_kernel
         res = {
             "metric": "input MS/s (complex) channelized",
             "value": round(value, 1),
@@ -216,26 +299,94 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: M={M} channels, {P} taps/branch, D={D}, {fmt} I/Q "
                                    f"({bw}-bit), 2^{args.log2_samples} samples per GPU per step, {'channel-major' if args.channel_major else 'frame-major'} complex64 out",
-                       "kernel": ch.last_kernel,
+                       "kernel": headline_kernel,
                        "schedule": args.schedule if args.schedule >= 0 else
                        ("default (channel-major route of the shape, DESIGN.md section 5.2)" if args.channel_major else
-                        "default (4: FIR/FFT wave pairs, 8x64-frame workgroups)" if M == 64 else "default (0: sliding runs)"),
+                        "default (4: FIR/FFT wave pairs, 8x64-frame workgroups)" if M == 64 else "default for the shape (DESIGN.md section 5.2)"),
                        "samples_per_gpu": n, "prewarm_steps": prewarm,
-                       "parallelism": f"time-sharded x{world}, halo {hist} samples/rank over RCCL" if world > 1 else "single GPU"},
+                       "parallelism": (f"time-sharded x{world}: one stream, rank r owns samples [r*n, (r+1)*n); halo {halo} raw samples "
+                                       f"({halo * bytes_in} B) per rank per step over {args.backend} ({args.halo}) on a side stream, "
+                                       f"interior frames first") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 per the guide's
+                         # gfx950 correction, WRITE_SIZE), never from this run: null here, the citation beside it
+                         "traffic": None, "traffic_source": TRAFFIC_SOURCE,
                          "kernel_ms": round(k_ms, 4), "launches_timed": len(kernel_ms),
-                         "algorithmic_bytes_per_sample": bytes_per_sample,
-                         "measured_stream_copy_gbs": round(copy_bps.value / 1e9, 1) if copy_rc == 0 else None},
+                         "launches_per_step": launches_per_step,
+                         "algorithmic_bytes_per_sample": bytes_per_sample},
         }
-        if world == 1 and not args.no_cpu_baseline and fmt == "int16":
-            prefix = iq[: 1 << 28].cpu().numpy()
+        tfile = os.path.join(ROOT, TRAFFIC_SOURCE)
+        if os.path.exists(tfile) and args.workload == "cfg2" and args.log2_samples == 30 and not args.channel_major:
+            try:
+                res["roofline"]["traffic_cited"] = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+
+        if world == 1:
+            # ---- sustained window: >= sustained_s seconds of back-to-back launches (clocks settle at sustained power)
+            if args.sustained_s > 0:
+                m = int(min(4000, max(100, args.sustained_s / (k_ms * 1e-3)))) if k_ms == k_ms else 0
+                if m:
+                    ch.set_option(L.PFB_OPT_PROFILE, 1)
+                    ts0 = time.perf_counter()
+                    for _ in range(m):
+                        step()
+                    ch.sync()
+                    wall = time.perf_counter() - ts0
+                    s_ms = float(np.mean(kernel_ms_per_step(ch, 1)))
+                    ch.set_option(L.PFB_OPT_PROFILE, 0)
+                    res["roofline"]["sustained_frac"] = round(n * bytes_per_sample / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    res["roofline"]["sustained_window_s"] = round(wall, 3)
+                    res["roofline"]["sustained_kernel_ms"] = round(s_ms, 4)
+            # ---- the yardstick: the fastest 1:2 streaming shape known on this part, same process, same box
+            copy_bps = L.C.c_double()
+            copy_rc = L.load().pfb_measure_stream_copy(local_rank, 1 << 30, 10, L.C.byref(copy_bps))
+            res["roofline"]["measured_stream_copy_gbs"] = round(copy_bps.value / 1e9, 1) if copy_rc == 0 else None
+        prefix = iq[: 1 << 28].cpu().numpy() if (world == 1 and not args.no_cpu_baseline and fmt == "int16") else None
+        ch.release()
+        del iq, out
+        torch.cuda.empty_cache()
+
+        # ---- the other BASELINE configurations, short timed passes (N = 1 only; cfg4 at its per-GPU size)
+        if world == 1 and not args.no_other_workloads and args.workload == "cfg2" and not args.channel_major:
+            others = []
+            for name, cm in OTHER_WORKLOADS:
+                oM, oP, oD, ofmt, obw, obytes, olog2 = WORKLOADS[name]
+                try:
+                    och, _ = make_handle(name, cm, tuned=False)
+                    oiq, oout = make_buffers(name, olog2, cm)
+                    for _ in range(12):
+                        och(oiq, out=oout, sync=False)
+                    och.sync()
+                    och.set_option(L.PFB_OPT_PROFILE, 1)
+                    for _ in range(20):
+                        och(oiq, out=oout, sync=False)
+                    och.sync()
+                    oms = float(np.mean(kernel_ms_per_step(och, 1)))
+                    ob = obytes + 8 * (oM // oD)
+                    ogbs = (1 << olog2) * ob / (oms * 1e-3) / 1e9
+                    others.append({"workload": name, "layout": "channel-major" if cm else "frame-major",
+                                   "shape": f"M={oM} P={oP} D={oD} {ofmt}, 2^{olog2} samples", "kernel": och.last_kernel,
+                                   "kernel_ms": round(oms, 4), "achieved": round(ogbs, 1), "frac": round(ogbs / HBM_PEAK_GBS, 4),
+                                   "ms_value": round((1 << olog2) / (oms * 1e-3) / 1e6, 1),
+                                   "algorithmic_bytes_per_sample": ob, "launches_timed": 20})
+                    och.release()
+                    del oiq, oout
+                    torch.cuda.empty_cache()
+                except Exception as e:  # a failing side workload must not cost the headline line
+                    others.append({"workload": name, "layout": "channel-major" if cm else "frame-major", "error": repr(e)})
+            res["other_workloads"] = others
+
+        if prefix is not None:
             res["cpu_baseline"] = cpu_baseline(prefix, taps, M, P, D, bw, args.cpu_budget_s)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    ch.release()
+    else:
+        ch.release()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

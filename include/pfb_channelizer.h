@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define PFB_ABI_VERSION 1
+#define PFB_ABI_VERSION 2
 
 typedef enum pfb_status {
   PFB_OK = 0,
@@ -62,7 +62,9 @@ typedef enum pfb_status {
   PFB_ERR_NO_DEVICE = -4,    /* no HIP device / HIP runtime unavailable              */
   PFB_ERR_HIP = -5,          /* a HIP call failed (pfb_last_error_detail has more)   */
   PFB_ERR_NO_MEMORY = -6,
-  PFB_ERR_CAPACITY = -7      /* output buffer smaller than the frames produced       */
+  PFB_ERR_CAPACITY = -7,     /* output buffer smaller than the frames produced       */
+  PFB_ERR_INTERNAL = -8,     /* a C++ exception other than bad_alloc was stopped at the ABI   */
+  PFB_ERR_COMM = -9          /* the caller's halo-exchange callback (RCCL) reported a failure */
 } pfb_status;
 
 typedef enum pfb_sample_format {
@@ -114,7 +116,8 @@ int pfb_create(const pfb_config* cfg, pfb_handle** out);
 int pfb_destroy(pfb_handle* h);
 /* zero the filter state, the carried tail and the frame counter */
 int pfb_reset(pfb_handle* h);
-/* launch on this hipStream_t from now on (default: the null stream) */
+/* launch on this hipStream_t from now on (default: the null stream).  Work already queued on the
+ * previous stream is ordered in front of whatever the new stream runs next for this handle. */
 int pfb_set_stream(pfb_handle* h, void* hip_stream);
 
 /* ---- process -------------------------------------------------------------- */
@@ -165,10 +168,61 @@ int pfb_set_state(pfb_handle* h, const void* buf, size_t bytes);
 int pfb_set_frame_index(pfb_handle* h, uint64_t next_frame);
 int pfb_get_frame_index(const pfb_handle* h, uint64_t* next_frame);
 
+/* ---- time-sharded streams: one segment per GPU ------------------------
+ * The reference channelizes a whole record in one call (matlab/create_pdws_channelized.m:57); a host
+ * that cuts the stream into G contiguous segments, one per GPU, needs exactly one exchange: the last
+ * pfb_halo_samples() RAW samples of segment g are the filter state of segment g+1.  The library
+ * orchestrates the step and leaves the transport to the caller, so it links no communication library
+ * itself: the callback is where a C++ host puts
+ *     ncclGroupStart(); ncclSend(d_send, bytes, ncclUint8, send_to, comm, stream);
+ *                       ncclRecv(d_recv, bytes, ncclUint8, recv_from, comm, stream); ncclGroupEnd();
+ * (examples/sharded_rccl.cpp; sdr_channelizer_amd/sharded.py does the same through torch.distributed).
+ * It must ENQUEUE both transfers on `hip_stream` and return without waiting; either side may be absent
+ * (rank < 0 and pointer NULL: the first shard of a non-ring stream receives nothing, the last sends
+ * nothing).  Return 0 on success; anything else makes the call fail with PFB_ERR_COMM. */
+typedef int (*pfb_halo_exchange_fn)(void* user, const void* d_send, void* d_recv, size_t bytes,
+                                    int send_to_rank, int recv_from_rank, void* hip_stream);
+typedef struct pfb_shard_config {
+  uint32_t struct_size;          /* = sizeof(pfb_shard_config)                                    */
+  int32_t rank, world;           /* this handle owns segment `rank` of `world`                    */
+  uint32_t ring;                 /* 1: rank 0 receives from rank world-1 (the segments of call i+1 */
+                                 /* follow those of call i: an endless stream, what bench.py times); */
+                                 /* 0: rank 0 continues from the handle's own state                */
+  pfb_halo_exchange_fn exchange; /* may be NULL when world == 1                                   */
+  void* user;
+} pfb_shard_config;
+/* Make the handle one shard of a time-sharded stream (world == 1 detaches). */
+int pfb_shard_attach(pfb_handle* h, const pfb_shard_config* cfg);
+/* Raw samples a shard needs from its predecessor: M*P - 1 - input_offset, i.e. (P-1)*M with the
+ * default input_offset D-1 at D = M -- the (taps_per_branch-1)*M overlap and nothing more. */
+uint64_t pfb_halo_samples(const pfb_handle* h);
+/* The first frames of a segment whose windows reach into the halo: ceil(pfb_history_samples / D). */
+uint64_t pfb_shard_head_frames(const pfb_handle* h);
+/* Where the predecessor's tail lands (device memory owned by the handle, pfb_halo_samples() samples
+ * of cfg.sample_format): what the library passes to the callback as d_recv. */
+void* pfb_halo_recv_buffer(pfb_handle* h);
+/* Channelize this rank's segment (device pointers; num_samples a multiple of D, at least
+ * pfb_shard_head_frames()+1 frames, carried tail empty).  Enqueued, no host sync:
+ *   side stream : the halo exchange (the callback), ordered behind what the handle's stream has queued
+ *   main stream : frames [head, F) -- every frame whose window lies inside the segment -- start at
+ *                 once; frames [0, head) follow when the halo has landed (one event wait on the GPU).
+ * The result is bit-identical to channelizing the whole stream on one device.  The handle's state
+ * afterwards is the segment's tail, as after pfb_process.  pfb_sync() also covers the transfers. */
+int pfb_process_shard_async(pfb_handle* h, const void* d_segment, uint64_t num_samples, void* d_out,
+                            uint64_t out_capacity_frames, uint64_t* frames_out);
+
 /* ---- helpers -------------------------------------------------------------- */
-/* centerFrequencies(channelizer, fs): out[k], unshifted order
- * [0,1,..,ceil(M/2)-1,-floor(M/2),..,-1]*fs/M. */
+/* centerFrequencies(channelizer, fs).  What order MathWorks' function returns is NOT pinned here
+ * (closed toolbox).  matlab/channelizer_example.m:58-66 plots
+ * fftshift(out,2) against fc - centerFrequencies(channelizer,fs), which only reads sensibly if the
+ * list is already centred and ascending; matlab/create_pdws_channelized.m:42,80 indexes it with the
+ * fftshift-ed column either way.  Both orders are offered:
+ *   PFB_FREQ_ORDER_FFT       out[k] = [0,1,..,ceil(M/2)-1,-floor(M/2),..,-1]*fs/M  (column k of `out`)
+ *   PFB_FREQ_ORDER_CENTERED  out[c] = (c - floor(M/2))*fs/M                        (column c of fftshift(out,2))
+ * pfb_center_frequencies is the FFT order (the frequency of UNSHIFTED output column k). */
+enum { PFB_FREQ_ORDER_FFT = 0, PFB_FREQ_ORDER_CENTERED = 1 };
 int pfb_center_frequencies(uint32_t num_channels, double fs, double* out);
+int pfb_center_frequencies_ordered(uint32_t num_channels, double fs, uint32_t order, double* out);
 /* Convenience prototype: Kaiser-windowed sinc, M*P taps, cutoff fs/(2M).
  * NOT verified against MathWorks' internal design -- pass your own taps for
  * parity work. */
@@ -218,7 +272,10 @@ int pfb_get_kernel_times(pfb_handle* h, float* ms_out, int capacity, int* count)
 const char* pfb_last_kernel(const pfb_handle* h);
 /* Device stream-copy (read 1 : write 2, like cfg 2's traffic) timed with HIP
  * events: bytes moved per second, for the "measured peak" next to the nominal
- * roofline.  Uses `bytes_in` of input and 2*bytes_in of output scratch. */
+ * roofline.  Uses `bytes_in` of input and 2*bytes_in of output scratch.  The kernel is the
+ * fastest 1:2 shape tools/membench2 found on MI355X (short-lived 4-wave workgroups, two 256-byte
+ * rows per wave, one 16-byte store per lane), so the figure is a yardstick no channelizer kernel
+ * with this byte mix should beat. */
 int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double* bytes_per_sec);
 
 /* Page-locked host memory for the sample and output buffers of PFB_MEM_HOST calls -- what the
@@ -228,6 +285,10 @@ int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double*
  * really overlap (pageable memory works, at the rate of the runtime's own staging).  NULL on failure. */
 void* pfb_host_alloc(size_t bytes);
 void pfb_host_free(void* p);
+/* Diagnostic: throws a C++ exception of the given kind (0 = std::bad_alloc, 1 = std::runtime_error,
+ * 2 = a non-std type) INSIDE the guard every entry point runs under and returns what the guard
+ * returns (PFB_ERR_NO_MEMORY / PFB_ERR_INTERNAL): proof that nothing thrown crosses the C ABI. */
+int pfb_selftest_exception_guard(int kind);
 
 /* ---- channelized PDW extraction ------------------------------------------------
  * Replaces the second half of matlab/create_pdws_channelized.m (lines 64-143): per-channel
@@ -249,13 +310,18 @@ typedef struct pfb_pdw {
 } pfb_pdw;
 
 enum {
-  /* reproduce the reference's two indexing quirks: the unshifted centre-frequency list is
-   * indexed with the shifted column (:42 vs :80) and phase(toa:jj) linear-indexes column 1
-   * (:114).  Without the flag the pulse's own column and its true centre frequency are used. */
+  /* reproduce the reference's indexing quirk at :114: phase(toa:jj) linear-indexes COLUMN 1 of the
+   * phase matrix whatever channel the pulse is in.  Without the flag the pulse's own column is used. */
   PFB_PDW_MATLAB_QUIRKS = 1u << 0,
   /* `y` is channel-major, y[k*frames + m]: MATLAB's own column-major F x M matrix (what pfb_process
    * writes for a PFB_LAYOUT_CHANNEL_MAJOR handle).  Transposed once into device scratch. */
-  PFB_PDW_CHANNEL_MAJOR = 1u << 1
+  PFB_PDW_CHANNEL_MAJOR = 1u << 1,
+  /* fc_chan = fc + binFreqs(bin) (:80) with binFreqs in FFT order (PFB_FREQ_ORDER_FFT) indexed by the
+   * fftshift-ed column -- what the script computes IF MathWorks' centerFrequencies returns the unshifted
+   * list; every pulse's freq is then half the band away from its channel.  Unpinned (see
+   * pfb_center_frequencies): the default is the column's true centre frequency, which is also what the
+   * script computes if centerFrequencies returns the centred list. */
+  PFB_PDW_BINFREQ_UNSHIFTED = 1u << 2
 };
 
 /* fs_in: sample rate BEFORE decimation; the frame rate used is fs_in/decimation (:62).

@@ -30,6 +30,10 @@ extern "C" {
 #define PFB_IQ_MARKER_FMT1 0x01010101u /* matlab/generate_training_iq.m:109, cpp/tx_rx_pulses_usrp.cpp:182 */
 #define PFB_IQ_MARKER_FMT2 0x02020202u /* cpp/blade_record_iq_12bit.cpp:248 */
 #define PFB_IQ_MARKER_FMT3 0x03030303u /* cpp/usrp_record_iq_12bit.cpp:159 */
+/* matlab/convert_my_iq_to_mat.m:42-45: marker 0 is announced as "big endian" and read as file format 2 --
+ * but the script never re-opens the file with another byte order, so every field is still read in native
+ * (little-endian) order.  No writer in the reference produces it; the parser does what the reader does. */
+#define PFB_IQ_MARKER_ZERO 0x00000000u
 #define PFB_IQ_HEADER_BYTES 112u
 #define PFB_IQ_HEADER_BYTES_FMT1 104u
 #define PFB_FILENAME_LENGTH 80 /* cpp/Helper.h:7 */
@@ -71,7 +75,7 @@ _Static_assert(offsetof(pfb_iq_packet, sampleStartTime) == 104, "offset");
 /* Parsed view of any of the three on-disk header variants. */
 typedef struct pfb_iq_info {
   pfb_iq_packet packet;       /* fields widened into the current (fmt 3) struct   */
-  int32_t  file_format;       /* 1, 2 or 3                                        */
+  int32_t  file_format;       /* 1, 2 or 3 (marker 0 reads as 2)                  */
   uint32_t header_bytes;      /* 104 or 112: payload starts here                  */
   uint32_t bytes_per_sample;  /* 2 (int8 I,Q) or 4 (int16 I,Q)                    */
   uint32_t sample_format;     /* PFB_FMT_INT8_IQ or PFB_FMT_INT16_IQ              */

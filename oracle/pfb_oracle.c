@@ -363,7 +363,8 @@ int pfbo_parse_iq_header(const uint8_t* b, size_t len, pfbo_iq_header* o) {
     case 0x01010101u: o->file_format = 1; break;
     case 0x02020202u: o->file_format = 2; break;
     case 0x03030303u: o->file_format = 3; break;
-    default: return -2; /* 0x00000000 (big endian) is not produced by any writer here */
+    case 0x00000000u: o->file_format = 2; break; /* :43-45: announced as big endian, read as format 2 in native order */
+    default: return -2;
   }
   o->header_bytes = (o->file_format == 1) ? 104u : 112u;
   if (len < o->header_bytes) return -3;
@@ -427,8 +428,10 @@ size_t pfbo_extract_pdws(const double* yr, const double* yi, size_t F, int M, in
   const double gain = pow(10.0, snr_threshold_db / 10.0); /* :74-75 (dB on magnitude with /10) */
   size_t count = 0;
   for (int b = 0; b < M; ++b) {
-    /* :80 indexes the UNSHIFTED centre-frequency list with the SHIFTED column */
-    const double f_bin = matlab_quirks ? bin_freqs[b] : bin_freqs[(b + (M + 1) / 2) % M];
+    /* :80 binFreqs(bin) with `bin` the column of the fftshift-ed matrix.  Bit 1: binFreqs is the FFT-ordered
+     * (unshifted) list -- what :42 yields IF MathWorks' centerFrequencies returns that order (unpinned);
+     * otherwise the column's true centre frequency (= the centred list indexed by the shifted column). */
+    const double f_bin = (matlab_quirks & 2) ? bin_freqs[b] : bin_freqs[(b + (M + 1) / 2) % M];
     const double fc_chan = fc + f_bin;
     const double thr = nf[b] * gain;
     int active = 0, saturated = 0;
@@ -442,7 +445,7 @@ size_t pfbo_extract_pdws(const double* yr, const double* yi, size_t F, int M, in
         const size_t len = j - toa + 1;
         for (size_t t = 0; t < len; ++t) tmp[t] = MAG(toa + t, b);
         const double amp = median_of(tmp, len);                /* :101 */
-        const int pcol = matlab_quirks ? 0 : b;                /* :114 linear index -> column 1 */
+        const int pcol = (matlab_quirks & 1) ? 0 : b;          /* :114 linear index -> column 1 (bit 0) */
         for (size_t t = 0; t + 1 < len; ++t) {
           double d = PHASE(toa + t + 1, pcol) - PHASE(toa + t, pcol);
           if (d < -180.0) d += 360.0;                          /* :115 */

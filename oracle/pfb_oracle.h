@@ -139,11 +139,13 @@ typedef struct {
 
 /* y: F x M complex, frame-major, already fftshift-ed (:60). fs_in is the rate
  * BEFORE decimation; the reference divides by M (fs <- fs/M, :62); decim carries the true
- * decimation so the 2x oversampled bank (decim = M/2) gets its real frame rate. bin_freqs are the UNSHIFTED
- * centre frequencies indexed with the SHIFTED column number exactly as the
- * reference does (:42 vs :60,:80) when matlab_quirks != 0; otherwise the
- * shifted (correct) centre frequency is used and phase(toa:jj) is taken from
- * the pulse's own column instead of column 1 (:114).
+ * decimation so the 2x oversampled bank (decim = M/2) gets its real frame rate.  matlab_quirks is a bit mask:
+ *   bit 0  phase(toa:jj) linear-indexes column 1 of the phase matrix (:114) instead of the pulse's column;
+ *   bit 1  binFreqs(bin) (:80) comes from the FFT-ordered (unshifted) centre-frequency list indexed with the
+ *          shifted column -- what the script computes IF MathWorks' centerFrequencies(channelizer,fs) (:42)
+ *          returns the unshifted list; unpinned (closed toolbox; channelizer_example.m:58-66 plots
+ *          fftshift(out,2) against that list, which suggests it is already centred).  Without the bit the
+ *          column's true centre frequency is used.
  * Returns the number of PDWs found; writes at most max_out of them. */
 size_t pfbo_extract_pdws(const double* yr, const double* yi, size_t F, int M, int decim,
                          double fs_in, double fc, double sample_start_time,

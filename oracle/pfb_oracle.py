@@ -181,14 +181,15 @@ class COracle:
         return d
 
     def extract_pdws(self, y: np.ndarray, fs_in: float, fc: float, start_time: float,
-                     snr_db: float = 15.0, matlab_quirks: bool = True, max_out: int = 1 << 16, decim: int | None = None):
+                     snr_db: float = 15.0, matlab_quirks: bool = True, max_out: int = 1 << 16, decim: int | None = None,
+                     binfreq_unshifted: bool = False):
         y = np.asarray(y, dtype=np.complex128)
         F, M = y.shape
         yr = np.ascontiguousarray(y.real).reshape(-1)
         yi = np.ascontiguousarray(y.imag).reshape(-1)
         buf = (_Pdw * max_out)()
         n = self.lib.pfbo_extract_pdws(yr, yi, F, M, M if decim is None else decim, fs_in, fc, start_time, snr_db,
-                                       int(matlab_quirks), buf, max_out)
+                                       int(bool(matlab_quirks)) | (2 if binfreq_unshifted else 0), buf, max_out)
         n = min(int(n), max_out)
         return [dict(toa=b.toa, freq=b.freq, pw=b.pw, snr=b.snr, sat=bool(b.sat), bin=b.bin, mag=b.mag) for b in buf[:n]]
 

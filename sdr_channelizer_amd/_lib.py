@@ -20,6 +20,10 @@ PFB_ERR_NO_DEVICE = -4
 PFB_ERR_HIP = -5
 PFB_ERR_NO_MEMORY = -6
 PFB_ERR_CAPACITY = -7
+PFB_ERR_INTERNAL = -8
+PFB_ERR_COMM = -9
+PFB_ABI_VERSION = 2
+PFB_FREQ_ORDER_FFT, PFB_FREQ_ORDER_CENTERED = 0, 1
 
 PFB_FMT_INT8_IQ, PFB_FMT_INT16_IQ, PFB_FMT_CF32 = 0, 1, 2
 PFB_LAYOUT_FRAME_MAJOR, PFB_LAYOUT_CHANNEL_MAJOR = 0, 1
@@ -54,8 +58,17 @@ class PfbPdw(C.Structure):
                 ("sat", C.c_int32), ("bin", C.c_int32), ("mag", C.c_double)]
 
 
-PFB_PDW_MATLAB_QUIRKS = 1
+PFB_PDW_MATLAB_QUIRKS = 1        # phase(toa:jj) linear-indexes column 1 (create_pdws_channelized.m:114)
 PFB_PDW_CHANNEL_MAJOR = 2
+PFB_PDW_BINFREQ_UNSHIFTED = 4    # binFreqs(bin) from the FFT-ordered list (:42/:80 if centerFrequencies is unshifted; unpinned)
+
+# int exchange(void* user, const void* d_send, void* d_recv, size_t bytes, int send_to, int recv_from, void* hip_stream)
+HALO_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
+
+
+class PfbShardConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("rank", C.c_int32), ("world", C.c_int32), ("ring", C.c_uint32),
+                ("exchange", HALO_EXCHANGE_FN), ("user", C.c_void_p)]
 
 
 class PfbIqInfo(C.Structure):
@@ -73,6 +86,8 @@ EXPORTS = (
     "pfb_last_error_detail", "pfb_abi_version", "pfb_device_count", "pfb_set_option", "pfb_last_kernel",
     "pfb_measure_stream_copy", "pfb_get_kernel_times", "pfb_host_alloc", "pfb_host_free", "pfb_pdw_extract", "pfb_pdw_extract_raw", "pfb_pdw_from_iq_file", "pfb_pdw_raw_from_iq_file", "pfb_pdw_last_error_detail", "pfb_pdw_release_workspace", "pfb_pdw_last_noise_floor_path",
     "pfb_iq_parse_header", "pfb_iq_fill_packet", "pfb_iq_filename",
+    "pfb_shard_attach", "pfb_halo_samples", "pfb_shard_head_frames", "pfb_halo_recv_buffer", "pfb_process_shard_async",
+    "pfb_center_frequencies_ordered", "pfb_selftest_exception_guard",
 )
 
 _lib = None
@@ -122,6 +137,16 @@ def load() -> C.CDLL:
     lib.pfb_set_frame_index.argtypes = [vp, u64]
     lib.pfb_get_frame_index.argtypes = [vp, C.POINTER(u64)]
     lib.pfb_center_frequencies.argtypes = [u32, C.c_double, C.POINTER(C.c_double)]
+    lib.pfb_center_frequencies_ordered.argtypes = [u32, C.c_double, u32, C.POINTER(C.c_double)]
+    lib.pfb_selftest_exception_guard.argtypes = [C.c_int]
+    lib.pfb_shard_attach.argtypes = [vp, C.POINTER(PfbShardConfig)]
+    lib.pfb_halo_samples.argtypes = [vp]
+    lib.pfb_halo_samples.restype = u64
+    lib.pfb_shard_head_frames.argtypes = [vp]
+    lib.pfb_shard_head_frames.restype = u64
+    lib.pfb_halo_recv_buffer.argtypes = [vp]
+    lib.pfb_halo_recv_buffer.restype = C.c_void_p
+    lib.pfb_process_shard_async.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
     lib.pfb_design_prototype.argtypes = [u32, u32, C.c_double, C.POINTER(C.c_float)]
     lib.pfb_strerror.argtypes = [C.c_int]
     lib.pfb_strerror.restype = C.c_char_p

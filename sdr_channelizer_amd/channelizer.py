@@ -50,10 +50,15 @@ def pinned_empty(shape, dtype):
     return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
 
 
-def center_frequencies(num_bands: int, fs: float) -> np.ndarray:
+def center_frequencies(num_bands: int, fs: float, order: str = "fft") -> np.ndarray:
+    """centerFrequencies(channelizer, fs).  order="fft": the frequency of unshifted output column k,
+    [0, 1, .., -1] * fs / M; order="centered": of column c of fftshift(out, 2), ascending from -fs/2.  Which of the two
+    MathWorks' function returns is not pinned here (closed toolbox): channelizer_example.m:58-66 plots the fftshift-ed
+    output against this list, which suggests "centered" (DESIGN.md section 4)."""
     out = np.empty(num_bands, dtype=np.float64)
-    L.check(L.load().pfb_center_frequencies(num_bands, fs, out.ctypes.data_as(C.POINTER(C.c_double))),
-            "pfb_center_frequencies")
+    code = {"fft": L.PFB_FREQ_ORDER_FFT, "centered": L.PFB_FREQ_ORDER_CENTERED}[order]
+    L.check(L.load().pfb_center_frequencies_ordered(num_bands, fs, code, out.ctypes.data_as(C.POINTER(C.c_double))),
+            "pfb_center_frequencies_ordered")
     return out
 
 
@@ -87,6 +92,8 @@ class Channelizer:
         self.channel_major = bool(channel_major)
         self.device = device
         self.magnitude = bool(magnitude)  # fused abs(channelizer(x)): float32 out
+        self.fftshift = bool(fftshift)
+        self._shard_cb = None  # keeps the ctypes halo-exchange callback alive while attached
         flags = (L.PFB_FLAG_FFTSHIFT if fftshift else 0) | (L.PFB_FLAG_CONJUGATE_INPUT if conjugate_input else 0) \
             | (L.PFB_FLAG_DEROTATE if derotate else 0) | (L.PFB_FLAG_MAGNITUDE if magnitude else 0)
         cfg = L.PfbConfig(C.sizeof(L.PfbConfig), M, self.taps_per_band, self.decimation,
@@ -95,6 +102,11 @@ class Channelizer:
                           int(input_offset), int(device))
         L.check(lib.pfb_create(C.byref(cfg), C.byref(self._h)), "pfb_create")
         self._lib = lib
+        if device >= 0:
+            self._device_index = int(device)
+        else:  # the library took the current device; ask torch (same runtime) which one that was
+            import torch
+            self._device_index = int(torch.cuda.current_device())
 
     # -- lifecycle ---------------------------------------------------------------
     def release(self) -> None:
@@ -120,8 +132,10 @@ class Channelizer:
         L.check(self._lib.pfb_reset(self._h), "pfb_reset")
 
     # -- helpers -----------------------------------------------------------------
-    def centerFrequencies(self, fs: float) -> np.ndarray:  # noqa: N802 (reference name)
-        return center_frequencies(self.num_bands, fs)
+    def centerFrequencies(self, fs: float, order: str | None = None) -> np.ndarray:  # noqa: N802 (reference name)
+        """Centre frequency of every output column of THIS handle: centred order when it fftshifts its output,
+        FFT order otherwise (override with order="fft" / "centered")."""
+        return center_frequencies(self.num_bands, fs, order or ("centered" if self.fftshift else "fft"))
 
     def frames_for(self, num_samples: int) -> int:
         f = C.c_uint64()
@@ -171,10 +185,35 @@ class Channelizer:
     def _is_torch(self, x) -> bool:
         return type(x).__module__.startswith("torch")
 
+    def _device_samples(self, iq) -> int:
+        """Validate a CUDA tensor of raw samples against the handle (dtype, device, contiguity) BEFORE its pointer goes
+        to the library -- a wrong dtype would be read at the handle's sample size, past the end of the allocation --
+        and return its length in complex samples."""
+        import torch
+        want = {L.PFB_FMT_INT8_IQ: (torch.int8,), L.PFB_FMT_INT16_IQ: (torch.int16,),
+                L.PFB_FMT_CF32: (torch.float32, torch.complex64)}[self.fmt]
+        if iq.dtype not in want:
+            raise TypeError(f"expected {want[0]} I/Q for this channelizer, got {iq.dtype}")
+        dev = self.device_index
+        if iq.device.index != dev:
+            raise ValueError(f"I/Q tensor is on cuda:{iq.device.index}, the channelizer on cuda:{dev}")
+        if not iq.is_contiguous():
+            raise ValueError("device I/Q must be contiguous")
+        if iq.is_complex():
+            return iq.numel()
+        if iq.numel() % 2 or (iq.dim() >= 2 and iq.shape[-1] != 2):
+            raise ValueError("interleaved I,Q: the last dimension must be 2 (or a flat tensor of even length)")
+        return iq.numel() // 2
+
+    @property
+    def device_index(self) -> int:
+        """The HIP device ordinal the handle lives on (device=-1 at construction = the device current at that moment)."""
+        return self._device_index
+
     def prime(self, iq) -> None:
         """Feed history without producing output (time-shard halo, resume)."""
         if self._is_torch(iq) and iq.is_cuda:
-            n = iq.numel() // 2 if not iq.is_complex() else iq.numel()
+            n = self._device_samples(iq)
             L.check(self._lib.pfb_prime(self._h, C.c_void_p(iq.data_ptr()), n, L.PFB_MEM_DEVICE), "pfb_prime")
             return
         a, n = self._host_samples(iq)
@@ -187,16 +226,15 @@ class Channelizer:
         M = self.num_bands
         if self._is_torch(iq) and iq.is_cuda:
             import torch
-            if not iq.is_contiguous():
-                raise ValueError("device I/Q must be contiguous")
-            n = iq.numel() if iq.is_complex() else iq.numel() // 2
+            n = self._device_samples(iq)
             F = self.frames_for(n)
             shape = (M, F) if self.channel_major else (F, M)
             odt = torch.float32 if self.magnitude else torch.complex64
             if out is None:
                 out = torch.empty(shape, dtype=odt, device=iq.device)
-            elif out.numel() < F * M or out.dtype != odt or not out.is_contiguous():
-                raise ValueError(f"out must be a contiguous {odt} tensor with room for frames*M values")
+            elif (not self._is_torch(out) or not out.is_cuda or out.device != iq.device or out.numel() < F * M
+                  or out.dtype != odt or not out.is_contiguous()):
+                raise ValueError(f"out must be a contiguous {odt} tensor on {iq.device} with room for frames*M values")
             f = C.c_uint64()
             fn = self._lib.pfb_process if sync else self._lib.pfb_process_async
             args = [self._h, C.c_void_p(iq.data_ptr()), n, C.c_void_p(out.data_ptr()), F, C.byref(f)]
@@ -207,11 +245,65 @@ class Channelizer:
         a, n = self._host_samples(iq)
         F = self.frames_for(n)
         shape = (M, F) if self.channel_major else (F, M)
-        res = np.empty(shape, dtype=np.float32 if self.magnitude else np.complex64) if out is None else out
+        odt = np.float32 if self.magnitude else np.complex64
+        if out is None:
+            res = np.empty(shape, dtype=odt)
+        else:  # the library writes F * M elements through this pointer: check before handing it over
+            if not isinstance(out, np.ndarray) or out.dtype != odt or out.size < F * M or not out.flags.c_contiguous:
+                raise ValueError("out must be a C-contiguous numpy array of the output dtype with room for frames*M values")
+            res = out if out.shape == shape else out.reshape(-1)[: F * M].reshape(shape)
         f = C.c_uint64()
         L.check(self._lib.pfb_process(self._h, C.c_void_p(a.ctypes.data), n, C.c_void_p(res.ctypes.data), F,
                                       C.byref(f), L.PFB_MEM_HOST), "pfb_process")
         return res
+
+    # -- time sharding (pfb_shard_attach / pfb_process_shard_async) -------------------
+    @property
+    def halo_samples(self) -> int:
+        """Raw samples a time shard needs from its predecessor: M*P - 1 - input_offset = (P-1)*M by default."""
+        return int(self._lib.pfb_halo_samples(self._h))
+
+    @property
+    def shard_head_frames(self) -> int:
+        return int(self._lib.pfb_shard_head_frames(self._h))
+
+    def attach_shard(self, rank: int, world: int, exchange=None, ring: bool = False) -> None:
+        """Make this handle segment ``rank`` of ``world``.  ``exchange(d_send, d_recv, nbytes, send_to, recv_from,
+        hip_stream) -> int`` enqueues the two transfers on ``hip_stream`` (pointers are ints, 0 / rank -1 = absent) and
+        returns 0; sdr_channelizer_amd.sharded.make_exchange builds one over torch.distributed."""
+        cb = L.HALO_EXCHANGE_FN(0)
+        if exchange is not None:
+            def _trampoline(_user, d_send, d_recv, nbytes, send_to, recv_from, stream):
+                try:
+                    return int(exchange(d_send or 0, d_recv or 0, int(nbytes), int(send_to), int(recv_from), stream or 0))
+                except Exception:  # an exception must not unwind through the C library
+                    import traceback
+                    traceback.print_exc()
+                    return -1
+            cb = L.HALO_EXCHANGE_FN(_trampoline)
+        cfg = L.PfbShardConfig(C.sizeof(L.PfbShardConfig), int(rank), int(world), 1 if ring else 0, cb, None)
+        L.check(self._lib.pfb_shard_attach(self._h, C.byref(cfg)), "pfb_shard_attach")
+        self._shard_cb = cb
+
+    def process_shard(self, segment, out=None):
+        """Channelize this rank's segment (CUDA tensor, whole frames): halo exchange on a side stream, interior frames at
+        once, head frames when the halo has landed.  Asynchronous; ``sync()`` waits for kernels and transfers."""
+        import torch
+        n = self._device_samples(segment)
+        if n % self.decimation:
+            raise ValueError("a shard is cut on frame boundaries: its length must be a multiple of the decimation")
+        F, M = n // self.decimation, self.num_bands
+        shape = (M, F) if self.channel_major else (F, M)
+        odt = torch.float32 if self.magnitude else torch.complex64
+        if out is None:
+            out = torch.empty(shape, dtype=odt, device=segment.device)
+        elif (not out.is_cuda or out.device != segment.device or out.numel() < F * M or out.dtype != odt
+              or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous {odt} tensor on {segment.device} with room for frames*M values")
+        f = C.c_uint64()
+        L.check(self._lib.pfb_process_shard_async(self._h, C.c_void_p(segment.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                                                  F, C.byref(f)), "pfb_process_shard_async")
+        return out if out.shape == shape else out.reshape(-1)[: F * M].reshape(shape)
 
     def kernel_times_ms(self) -> list[float]:
         """Durations of the channelizer kernel launches recorded since PFB_OPT_PROFILE was set."""

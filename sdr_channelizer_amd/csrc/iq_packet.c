@@ -26,7 +26,8 @@ int pfb_iq_parse_header(const void* bytes, size_t len, pfb_iq_info* out) {
     case PFB_IQ_MARKER_FMT1: out->file_format = 1; break;
     case PFB_IQ_MARKER_FMT2: out->file_format = 2; break;
     case PFB_IQ_MARKER_FMT3: out->file_format = 3; break;
-    default: return PFB_ERR_BAD_FORMAT; /* incl. 0x00000000: no big-endian writer exists */
+    case PFB_IQ_MARKER_ZERO: out->file_format = 2; break; /* :43-45 "assume latest file format"; fields stay little-endian */
+    default: return PFB_ERR_BAD_FORMAT;                   /* :55-56 error(...) */
   }
   out->header_bytes = out->file_format == 1 ? PFB_IQ_HEADER_BYTES_FMT1 : PFB_IQ_HEADER_BYTES;
   if (len < out->header_bytes) return PFB_ERR_BAD_ARG;

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <utility>
 #include <thread>
@@ -110,6 +111,15 @@ struct pfb_handle {
   int opt_profile = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // reusable pairs
   size_t ev_used = 0;
+  // time sharding (pfb_shard_attach): this handle owns segment shard_rank of shard_world
+  int shard_rank = 0, shard_world = 1;
+  bool shard_ring = false;
+  pfb_halo_exchange_fn shard_exchange = nullptr;
+  void* shard_user = nullptr;
+  void* d_halo = nullptr;            // hist_samples raw samples; the predecessor's tail lands in its last halo_samples
+  hipStream_t s_halo = nullptr;      // side stream of the exchange
+  hipEvent_t ev_seg = nullptr, ev_halo = nullptr;
+  hipEvent_t ev_switch = nullptr;    // pfb_set_stream: orders the old stream's work in front of the new stream's
 };
 
 namespace {
@@ -129,8 +139,13 @@ void free_handle(pfb_handle* h) {
   (void)hipFree(h->d_stage_out2);
   (void)hipFree(h->d_slab);
   (void)hipFree(h->d_matrix);
+  (void)hipFree(h->d_halo);
   if (h->s_in) (void)hipStreamDestroy(h->s_in);
   if (h->s_out) (void)hipStreamDestroy(h->s_out);
+  if (h->s_halo) (void)hipStreamDestroy(h->s_halo);
+  if (h->ev_seg) (void)hipEventDestroy(h->ev_seg);
+  if (h->ev_halo) (void)hipEventDestroy(h->ev_halo);
+  if (h->ev_switch) (void)hipEventDestroy(h->ev_switch);
   for (int i = 0; i < 2; ++i) {
     if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]);
     if (h->ev_k[i]) (void)hipEventDestroy(h->ev_k[i]);
@@ -142,115 +157,134 @@ void free_handle(pfb_handle* h) {
 
 uint64_t frames_for(const pfb_handle* h, uint64_t n) { return (h->phase + n) / (uint64_t)h->D; }
 
-// enqueue kernel + history update for device-resident buffers; no host sync
-int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t frames, int64_t out_ld,
-            int64_t out_frame0) {
-  if (frames > 0) {
-    pfb::KernelParams p{};
-    p.in = d_iq;
-    p.hist = h->d_hist[h->cur];
-    p.out = static_cast<float2*>(d_out);
-    p.taps = h->d_taps;
-    p.tw = h->d_tw;
-    p.taps_lane = h->d_taps_lane;
-    p.tw_lane = h->d_tw_lane;
-    p.n_in = (long long)n;
-    p.frames = (long long)frames;
-    p.frame0 = (long long)h->frame_index;
-    p.out_ld = out_ld;
-    p.out_frame0 = out_frame0;
-    p.base = (h->off - (int)h->phase) - (h->D - 1);
-    p.hist_samples = h->hist_samples;
-    p.M = h->M; p.P = h->P; p.D = h->D;
-    p.fmt = h->fmt;
-    p.layout = h->layout;
-    p.flags = h->flags;
-    p.nontemporal = h->opt_nontemporal;
-    p.xcd_remap = h->opt_xcd_remap < 0 ? 1 : h->opt_xcd_remap;
-    p.experiment = h->opt_experiment;
-    p.grid_override = h->opt_grid;
-    p.tile_waves = h->opt_tile_waves;
-    const bool want_fast = h->fast && h->opt_kernel != 1;
-    if (h->opt_kernel == 2 && !want_fast) return PFB_ERR_UNSUPPORTED;
-    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-    if (h->opt_profile && h->ev_used < 4096) {
-      if (h->ev_used == h->ev_pool.size()) {
-        hipEvent_t a = nullptr, b = nullptr;
-        HIP_TRY(hipEventCreate(&a));
-        HIP_TRY(hipEventCreate(&b));
-        h->ev_pool.emplace_back(a, b);
-      }
-      ev = &h->ev_pool[h->ev_used++];
-      HIP_TRY(hipEventRecord(ev->first, h->stream));
-    }
-    // Channel-major output of a fused shape is written by the kernel itself (its transposed-tile or plain
-    // channel-major instantiation).  The team plans (M = 1024, 560) have none -- their chunks of 4 frames would be
-    // 32-byte runs -- and go by slabs instead: the frame-major kernel fills a scratch slab, a transpose kernel
-    // moves it into place (M = 1024: 2x the 8-wave plan's fused channel-major stores).  A slab must be long enough
-    // to fill the chip with runs, so it does not fit the memory-side cache; PFB_OPT_SCHEDULE 9 forces the slabs on
-    // any shape, PFB_OPT_SLAB_FRAMES sets their length.
-    const bool cm = h->layout == PFB_LAYOUT_CHANNEL_MAJOR;
-    const bool forced_fused = h->opt_schedule == 0 || h->opt_schedule == 2 || h->opt_schedule == 8;
-    const bool by_slabs = cm && want_fast && (!h->fast->channel_major_ok || h->opt_schedule == 9);
-    if (want_fast) {
-      const int c = h->fast->chunk_frames;
-      int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
-      fpb = ((fpb + c - 1) / c) * c;
-      p.schedule = (h->opt_schedule >= 0 && h->opt_schedule != 9) ? h->opt_schedule : h->fast->default_schedule;
-      if (h->opt_schedule < 0 && (h->flags & PFB_FLAG_MAGNITUDE) && h->fast->magnitude_schedule >= 0 && !cm) {
-        p.schedule = h->fast->magnitude_schedule;  // fused abs(): magnitudes staged in LDS, sliding runs
-      }
-      if (cm && !by_slabs)  // fused channel-major: 0 = sliding runs, 2 = tiles, 8 = short runs transposed in LDS, else the kernel's pick
-        p.schedule = forced_fused ? h->opt_schedule : -1;
-      if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
-      if (p.schedule == 6 || p.schedule == 7) fpb = ((fpb + 2 * c - 1) / (2 * c)) * (2 * c);  // these kernels walk chunks in pairs
-      if (p.schedule == 4 || p.schedule == 5) {
-        if (h->opt_frames_per_block <= 0) fpb = 64;
-        if (h->opt_xcd_remap < 0) p.xcd_remap = 0;  // 512-frame workgroups: one dense sweep beats L2 halo hits
-      }
-      // short sliding runs in dispatch order already sweep the stream as one window: leave them round-robin over the XCDs
-      if (p.schedule == 0 && fpb <= 64 && h->opt_xcd_remap < 0) p.xcd_remap = 0;
-      p.frames_per_block = fpb;
-      const int cpt = h->fast->cols_per_thread;
-      const int bmod = ((p.base % cpt) + cpt) % cpt;
-      p.vec_ok = (bmod == 0) && (reinterpret_cast<uintptr_t>(d_iq) % (uintptr_t)(h->bps * cpt) == 0);
-      if (by_slabs) {
-        long long sf = h->opt_slab_frames > 0 ? h->opt_slab_frames : (long long)h->num_cus * fpb;  // one run per CU
-        sf = std::max<long long>(64, (sf + 63) / 64 * 64);
-        sf = std::max<long long>(sf, (h->hist_samples + h->D - 1) / h->D + 1);  // a later slab's window reaches back into the input, never into the history
-        sf = std::min<long long>(sf, 65535ll * 64);  // the transpose kernel's grid: one row of 64 x 64 tiles per 64 frames
-        sf = std::min<long long>(sf, ((long long)frames + 63) / 64 * 64);
-        const size_t need = (size_t)sf * h->M * h->out_elem;
-        if (need > h->slab_bytes) {
-          HIP_TRY(hipStreamSynchronize(h->stream));
-          (void)hipFree(h->d_slab);
-          h->d_slab = nullptr; h->slab_bytes = 0;
-          HIP_TRY(hipMalloc(&h->d_slab, need));
-          h->slab_bytes = need;
-        }
-        for (long long f0 = 0; f0 < (long long)frames; f0 += sf) {
-          pfb::KernelParams q = p;
-          q.layout = PFB_LAYOUT_FRAME_MAJOR;
-          q.out = static_cast<float2*>(h->d_slab);
-          q.frames = std::min<long long>(sf, (long long)frames - f0);
-          q.frame0 = p.frame0 + f0;
-          q.in = static_cast<const char*>(d_iq) + (size_t)f0 * h->D * h->bps;
-          q.n_in = (long long)n - f0 * h->D;
-          if (f0 > 0)  // "history" of a later slab = the input samples in front of it
-            q.hist = static_cast<const char*>(q.in) - (size_t)h->hist_samples * h->bps;
-          HIP_TRY(h->fast->launch(q, h->stream));
-          HIP_TRY(pfb::launch_transpose_slab(h->d_slab, q.frames, h->M, d_out, out_ld, out_frame0 + f0, h->out_elem, h->stream));
-        }
-      } else {
-        HIP_TRY(h->fast->launch(p, h->stream));
-      }
-      h->last_kernel = h->fast->name;
-    } else {
-      HIP_TRY(pfb::launch_generic(p, h->stream));
-      h->last_kernel = "pfb_generic";
-    }
-    if (ev) HIP_TRY(hipEventRecord(ev->second, h->stream));
+// Launch the channelizer kernel(s) for local frames [f_begin, f_end) of a device buffer of n samples.  `hist` holds
+// the hist_samples raw samples in front of d_iq[0]; it is only read when f_begin == 0 (a later range starts at
+// least hist_samples into the buffer, so its "history" is the buffer itself).  Output row f lands where a call
+// over the whole buffer would put it.  No state change, no host sync.
+int launch_frames(pfb_handle* h, const void* d_iq, uint64_t n, const void* hist, void* d_out, uint64_t f_begin,
+                  uint64_t f_end, int64_t out_ld, int64_t out_frame0) {
+  if (f_end <= f_begin) return PFB_OK;
+  if (f_begin > 0) {
+    if (f_begin * (uint64_t)h->D < (uint64_t)h->hist_samples) return PFB_ERR_BAD_ARG;
+    const size_t skip = (size_t)f_begin * h->D * h->bps;
+    hist = static_cast<const char*>(d_iq) + skip - (size_t)h->hist_samples * h->bps;
+    d_iq = static_cast<const char*>(d_iq) + skip;
+    n -= f_begin * (uint64_t)h->D;
+    if (h->layout == PFB_LAYOUT_FRAME_MAJOR) d_out = static_cast<char*>(d_out) + (size_t)f_begin * h->M * h->out_elem;
+    else out_frame0 += (int64_t)f_begin;
   }
+  const uint64_t frames = f_end - f_begin;
+  pfb::KernelParams p{};
+  p.in = d_iq;
+  p.hist = hist;
+  p.out = static_cast<float2*>(d_out);
+  p.taps = h->d_taps;
+  p.tw = h->d_tw;
+  p.taps_lane = h->d_taps_lane;
+  p.tw_lane = h->d_tw_lane;
+  p.n_in = (long long)n;
+  p.frames = (long long)frames;
+  p.frame0 = (long long)(h->frame_index + f_begin);
+  p.out_ld = out_ld;
+  p.out_frame0 = out_frame0;
+  p.base = (h->off - (int)h->phase) - (h->D - 1);
+  p.hist_samples = h->hist_samples;
+  p.M = h->M; p.P = h->P; p.D = h->D;
+  p.fmt = h->fmt;
+  p.layout = h->layout;
+  p.flags = h->flags;
+  p.nontemporal = h->opt_nontemporal;
+  p.xcd_remap = h->opt_xcd_remap < 0 ? 1 : h->opt_xcd_remap;
+  p.experiment = h->opt_experiment;
+  p.grid_override = h->opt_grid;
+  p.tile_waves = h->opt_tile_waves;
+  const bool want_fast = h->fast && h->opt_kernel != 1;
+  if (h->opt_kernel == 2 && !want_fast) return PFB_ERR_UNSUPPORTED;
+  hipEvent_t ev_first = nullptr, ev_second = nullptr;
+  if (h->opt_profile && h->ev_used < 4096) {
+    if (h->ev_used == h->ev_pool.size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      HIP_TRY(hipEventCreate(&a));
+      if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return hip_fail(hipGetLastError(), "hipEventCreate"); }
+      h->ev_pool.emplace_back(a, b);
+    }
+    ev_first = h->ev_pool[h->ev_used].first;
+    ev_second = h->ev_pool[h->ev_used].second;
+    HIP_TRY(hipEventRecord(ev_first, h->stream));
+    ++h->ev_used;  // only a pair whose first event was recorded counts as used
+  }
+  // Channel-major output of a fused shape is written by the kernel itself (its transposed-tile or plain
+  // channel-major instantiation).  The team plans (M = 1024, 560) have none -- their chunks of 4 frames would be
+  // 32-byte runs -- and go by slabs instead: the frame-major kernel fills a scratch slab, a transpose kernel
+  // moves it into place (M = 1024: 2x the 8-wave plan's fused channel-major stores).  A slab must be long enough
+  // to fill the chip with runs, so it does not fit the memory-side cache; PFB_OPT_SCHEDULE 9 forces the slabs on
+  // any shape, PFB_OPT_SLAB_FRAMES sets their length.
+  const bool cm = h->layout == PFB_LAYOUT_CHANNEL_MAJOR;
+  const bool forced_fused = h->opt_schedule == 0 || h->opt_schedule == 2 || h->opt_schedule == 8;
+  const bool by_slabs = cm && want_fast && (!h->fast->channel_major_ok || h->opt_schedule == 9);
+  if (want_fast) {
+    const int c = h->fast->chunk_frames;
+    int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
+    fpb = ((fpb + c - 1) / c) * c;
+    p.schedule = (h->opt_schedule >= 0 && h->opt_schedule != 9) ? h->opt_schedule : h->fast->default_schedule;
+    if (h->opt_schedule < 0 && (h->flags & PFB_FLAG_MAGNITUDE) && h->fast->magnitude_schedule >= 0 && !cm) {
+      p.schedule = h->fast->magnitude_schedule;  // fused abs(): magnitudes staged in LDS, sliding runs
+    }
+    if (cm && !by_slabs)  // fused channel-major: 0 = sliding runs, 2 = tiles, 8 = short runs transposed in LDS, else the kernel's pick
+      p.schedule = forced_fused ? h->opt_schedule : -1;
+    if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
+    if (p.schedule == 6 || p.schedule == 7) fpb = ((fpb + 2 * c - 1) / (2 * c)) * (2 * c);  // these kernels walk chunks in pairs
+    if (p.schedule == 4 || p.schedule == 5) {
+      if (h->opt_frames_per_block <= 0) fpb = 64;
+      if (h->opt_xcd_remap < 0) p.xcd_remap = 0;  // 512-frame workgroups: one dense sweep beats L2 halo hits
+    }
+    // short sliding runs in dispatch order already sweep the stream as one window: leave them round-robin over the XCDs
+    if (p.schedule == 0 && fpb <= 64 && h->opt_xcd_remap < 0) p.xcd_remap = 0;
+    p.frames_per_block = fpb;
+    const int cpt = h->fast->cols_per_thread;
+    const int bmod = ((p.base % cpt) + cpt) % cpt;
+    p.vec_ok = (bmod == 0) && (reinterpret_cast<uintptr_t>(d_iq) % (uintptr_t)(h->bps * cpt) == 0);
+    if (by_slabs) {
+      long long sf = h->opt_slab_frames > 0 ? h->opt_slab_frames : (long long)h->num_cus * fpb;  // one run per CU
+      sf = std::max<long long>(64, (sf + 63) / 64 * 64);
+      sf = std::max<long long>(sf, (h->hist_samples + h->D - 1) / h->D + 1);  // a later slab's window reaches back into the input, never into the history
+      sf = std::min<long long>(sf, 65535ll * 64);  // the transpose kernel's grid: one row of 64 x 64 tiles per 64 frames
+      sf = std::min<long long>(sf, ((long long)frames + 63) / 64 * 64);
+      const size_t need = (size_t)sf * h->M * h->out_elem;
+      if (need > h->slab_bytes) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_slab);
+        h->d_slab = nullptr; h->slab_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_slab, need));
+        h->slab_bytes = need;
+      }
+      for (long long f0 = 0; f0 < (long long)frames; f0 += sf) {
+        pfb::KernelParams q = p;
+        q.layout = PFB_LAYOUT_FRAME_MAJOR;
+        q.out = static_cast<float2*>(h->d_slab);
+        q.frames = std::min<long long>(sf, (long long)frames - f0);
+        q.frame0 = p.frame0 + f0;
+        q.in = static_cast<const char*>(d_iq) + (size_t)f0 * h->D * h->bps;
+        q.n_in = (long long)n - f0 * h->D;
+        if (f0 > 0)  // "history" of a later slab = the input samples in front of it
+          q.hist = static_cast<const char*>(q.in) - (size_t)h->hist_samples * h->bps;
+        HIP_TRY(h->fast->launch(q, h->stream));
+        HIP_TRY(pfb::launch_transpose_slab(h->d_slab, q.frames, h->M, d_out, out_ld, out_frame0 + f0, h->out_elem, h->stream));
+      }
+    } else {
+      HIP_TRY(h->fast->launch(p, h->stream));
+    }
+    h->last_kernel = h->fast->name;
+  } else {
+    HIP_TRY(pfb::launch_generic(p, h->stream));
+    h->last_kernel = "pfb_generic";
+  }
+  if (ev_second) HIP_TRY(hipEventRecord(ev_second, h->stream));
+  return PFB_OK;
+}
+
+// carry the last hist_samples raw samples of [history | d_iq] and advance the counters
+int advance_state(pfb_handle* h, const void* d_iq, uint64_t n, uint64_t frames) {
   if (n > 0) {
     HIP_TRY(pfb::launch_update_history(h->d_hist[h->cur], d_iq, (long long)n, h->d_hist[h->cur ^ 1],
                                        h->hist_samples, h->bps, h->stream));
@@ -259,6 +293,14 @@ int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t f
   h->phase = (uint32_t)((h->phase + n) % (uint64_t)h->D);
   h->frame_index += frames;
   return PFB_OK;
+}
+
+// enqueue kernel + history update for device-resident buffers; no host sync
+int enqueue(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t frames, int64_t out_ld,
+            int64_t out_frame0) {
+  const int rc = launch_frames(h, d_iq, n, h->d_hist[h->cur], d_out, 0, frames, out_ld, out_frame0);
+  if (rc != PFB_OK) return rc;
+  return advance_state(h, d_iq, n, frames);
 }
 
 int ensure_stage(pfb_handle* h, size_t in_bytes, size_t out_bytes, bool both_sets = false) {
@@ -288,8 +330,25 @@ int ensure_stage(pfb_handle* h, size_t in_bytes, size_t out_bytes, bool both_set
 // device_out: `out` is device memory (frame-major rows follow each other; channel-major as above): nothing is
 // copied back and the call returns once the input has left the host buffer, the kernels still queued on the
 // handle's stream.
+int process_host_pipeline(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t frames_total, uint64_t out_ld,
+                          uint64_t out_row0, bool device_out);
+
 int process_host(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t frames_total, uint64_t out_ld,
                  uint64_t out_row0, bool device_out = false) {
+  const int rc = process_host_pipeline(h, iq, n, out, frames_total, out_ld, out_row0, device_out);
+  if (rc != PFB_OK) {
+    // a failed step returned from the middle of the pipeline: copies to and from the CALLER's buffers may still be
+    // in flight on the three streams -- drain them before the caller is told it may free or reuse those buffers
+    if (h->s_in) (void)hipStreamSynchronize(h->s_in);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->s_out) (void)hipStreamSynchronize(h->s_out);
+    (void)hipGetLastError();
+  }
+  return rc;
+}
+
+int process_host_pipeline(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t frames_total, uint64_t out_ld,
+                          uint64_t out_row0, bool device_out) {
   // Stage through device buffers in chunks (multiples of D so chunks never change the carried phase
   // pattern mid-call beyond what the stream semantics already define).  Three streams and two buffer
   // sets: chunk i+1 is copied in while chunk i is transformed and chunk i-1 is copied out, so a caller
@@ -385,6 +444,8 @@ const char* pfb_strerror(int status) {
     case PFB_ERR_HIP: return "HIP runtime error";
     case PFB_ERR_NO_MEMORY: return "out of memory";
     case PFB_ERR_CAPACITY: return "output buffer too small";
+    case PFB_ERR_INTERNAL: return "internal error (C++ exception stopped at the ABI)";
+    case PFB_ERR_COMM: return "halo exchange callback failed";
     default: return "unknown status";
   }
 }
@@ -405,6 +466,23 @@ int pfb_center_frequencies(uint32_t M, double fs, double* out) {
     out[k] = (double)kk * fs / (double)M;
   }
   return PFB_OK;
+}
+
+int pfb_center_frequencies_ordered(uint32_t M, double fs, uint32_t order, double* out) {
+  if (!out || M == 0 || order > PFB_FREQ_ORDER_CENTERED) return PFB_ERR_BAD_ARG;
+  if (order == PFB_FREQ_ORDER_FFT) return pfb_center_frequencies(M, fs, out);
+  for (uint32_t c = 0; c < M; ++c)  // column c of fftshift(out,2) is FFT column (c + ceil(M/2)) mod M
+    out[c] = ((double)c - (double)(M / 2)) * fs / (double)M;
+  return PFB_OK;
+}
+
+int pfb_selftest_exception_guard(int kind) {
+  return pfb::abi_guard([&]() -> int {
+    if (kind == 0) throw std::bad_alloc();
+    if (kind == 1) throw std::runtime_error("pfb_selftest_exception_guard");
+    if (kind == 2) throw 42;
+    return PFB_OK;
+  });
 }
 
 static double bessel_i0(double x) {
@@ -437,6 +515,7 @@ int pfb_design_prototype(uint32_t M, uint32_t P, double atten_db, float* taps) {
 }
 
 int pfb_create(const pfb_config* cfg, pfb_handle** out) {
+  return pfb::abi_guard([&]() -> int {
   if (!cfg || !out) return PFB_ERR_BAD_ARG;
   *out = nullptr;
   if (cfg->struct_size != sizeof(pfb_config) || !cfg->taps) return PFB_ERR_BAD_ARG;
@@ -524,15 +603,19 @@ int pfb_create(const pfb_config* cfg, pfb_handle** out) {
   }
   *out = h;
   return PFB_OK;
+  });
 }
 
 int pfb_destroy(pfb_handle* h) {
+  return pfb::abi_guard([&]() -> int {
   if (!h) return PFB_ERR_BAD_ARG;
   free_handle(h);
   return PFB_OK;
+  });
 }
 
 int pfb_reset(pfb_handle* h) {
+  return pfb::abi_guard([&]() -> int {
   if (!h) return PFB_ERR_BAD_ARG;
   DeviceGuard g(h->device);
   const size_t hist_bytes = (size_t)h->hist_samples * h->bps;
@@ -540,12 +623,22 @@ int pfb_reset(pfb_handle* h) {
   h->phase = 0;
   h->frame_index = 0;
   return PFB_OK;
+  });
 }
 
 int pfb_set_stream(pfb_handle* h, void* hip_stream) {
+  return pfb::abi_guard([&]() -> int {
   if (!h) return PFB_ERR_BAD_ARG;
-  h->stream = static_cast<hipStream_t>(hip_stream);
+  hipStream_t next = static_cast<hipStream_t>(hip_stream);
+  if (next != h->stream) {  // what the old stream still has queued for this handle (kernels, the history update) comes first
+    DeviceGuard g(h->device);
+    if (!h->ev_switch) HIP_TRY(hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->ev_switch, h->stream));
+    HIP_TRY(hipStreamWaitEvent(next, h->ev_switch, 0));
+    h->stream = next;
+  }
   return PFB_OK;
+  });
 }
 
 int pfb_frames_for(const pfb_handle* h, uint64_t n, uint64_t* frames_out) {
@@ -556,6 +649,7 @@ int pfb_frames_for(const pfb_handle* h, uint64_t n, uint64_t* frames_out) {
 
 int pfb_process_async(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t cap,
                       uint64_t* frames_out) {
+  return pfb::abi_guard([&]() -> int {
   if (!h || (n > 0 && !d_iq)) return PFB_ERR_BAD_ARG;
   const uint64_t f = frames_for(h, n);
   if (frames_out) *frames_out = f;
@@ -563,17 +657,21 @@ int pfb_process_async(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, 
   if (f > 0 && !d_out) return PFB_ERR_BAD_ARG;
   DeviceGuard g(h->device);
   return enqueue(h, d_iq, n, d_out, f, (int64_t)f, 0);
+  });
 }
 
 int pfb_sync(pfb_handle* h) {
+  return pfb::abi_guard([&]() -> int {
   if (!h) return PFB_ERR_BAD_ARG;
   DeviceGuard g(h->device);
   HIP_TRY(hipStreamSynchronize(h->stream));
   return PFB_OK;
+  });
 }
 
 int pfb_process(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t cap, uint64_t* frames_out,
                 uint32_t mem) {
+  return pfb::abi_guard([&]() -> int {
   if (!h || (n > 0 && !iq) || mem > PFB_MEM_DEVICE) return PFB_ERR_BAD_ARG;
   const uint64_t f = frames_for(h, n);
   if (frames_out) *frames_out = f;
@@ -587,6 +685,7 @@ int pfb_process(pfb_handle* h, const void* iq, uint64_t n, void* out, uint64_t c
     return PFB_OK;
   }
   return process_host(h, iq, n, out, f, f, 0);
+  });
 }
 
 namespace {
@@ -696,9 +795,10 @@ int stream_record(pfb_handle* h, int fd, const pfb_iq_info& info, void* out, uin
 
 int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap, uint64_t* frames_out,
                         pfb_iq_info* info_out) {
+  return pfb::abi_guard([&]() -> int {
   if (!h || !path) return PFB_ERR_BAD_ARG;
   int fd = -1;
-  pfb_iq_info info;
+  pfb_iq_info info{};  // zeroed: copied out below even when the record could not be opened
   int rc = open_record(h, path, &fd, &info);
   if (info_out) *info_out = info;
   if (rc != PFB_OK) return rc;
@@ -709,15 +809,17 @@ int pfb_process_iq_file(pfb_handle* h, const char* path, void* out, uint64_t cap
   rc = stream_record(h, fd, info, out, need, false, frames_out);
   ::close(fd);
   return rc;
+  });
 }
 
 int pfb_pdw_from_iq_file(pfb_handle* h, const char* path, double snr_threshold_db, uint32_t pdw_flags, pfb_pdw* out,
                          uint64_t capacity, uint64_t* count, double* noise_floor_out, pfb_iq_info* info_out) {
+  return pfb::abi_guard([&]() -> int {
   if (!h || !path || !count || (capacity > 0 && !out)) return PFB_ERR_BAD_ARG;
   // the PDW stage reads a frame-major complex matrix (mag = abs(iq), phase = angle(iq), :67-68)
   if (h->layout != PFB_LAYOUT_FRAME_MAJOR || (h->flags & PFB_FLAG_MAGNITUDE)) return PFB_ERR_UNSUPPORTED;
   int fd = -1;
-  pfb_iq_info info;
+  pfb_iq_info info{};  // zeroed: copied out below even when the record could not be opened
   int rc = open_record(h, path, &fd, &info);
   if (info_out) *info_out = info;
   if (rc != PFB_OK) return rc;
@@ -745,11 +847,13 @@ int pfb_pdw_from_iq_file(pfb_handle* h, const char* path, double snr_threshold_d
   return pfb_pdw_extract(h->d_matrix, frames, (uint32_t)h->M, (uint32_t)h->D, (double)info.packet.sampleRateSps,
                          (double)info.packet.frequencyHz, info.packet.sampleStartTime, snr_threshold_db, pdw_flags, out,
                          capacity, count, noise_floor_out, PFB_MEM_DEVICE, h->device, h->stream);
+  });
 }
 
 int pfb_pdw_raw_from_iq_file(const char* path, double snr_threshold_db, double trailing_threshold_db, pfb_pdw* out,
                              uint64_t capacity, uint64_t* count, double* noise_floor_out, pfb_iq_info* info_out,
                              int32_t device_id) {
+  return pfb::abi_guard([&]() -> int {
   if (!path || !count || (capacity > 0 && !out)) return PFB_ERR_BAD_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return PFB_ERR_NO_DEVICE; }
@@ -757,7 +861,7 @@ int pfb_pdw_raw_from_iq_file(const char* path, double snr_threshold_db, double t
   if (dev < 0) HIP_TRY(hipGetDevice(&dev));
   if (dev >= ndev) return PFB_ERR_BAD_ARG;
   int fd = -1;
-  pfb_iq_info info;
+  pfb_iq_info info{};
   int rc = open_record(nullptr, path, &fd, &info);
   if (info_out) *info_out = info;
   if (rc != PFB_OK) return rc;
@@ -810,11 +914,13 @@ int pfb_pdw_raw_from_iq_file(const char* path, double snr_threshold_db, double t
                            trailing_threshold_db, out, capacity, count, noise_floor_out, PFB_MEM_DEVICE, dev, st);
   cleanup();
   return rc;
+  });
 }
 
 uint64_t pfb_history_samples(const pfb_handle* h) { return h ? (uint64_t)h->hist_samples : 0; }
 
 int pfb_prime(pfb_handle* h, const void* iq, uint64_t n, uint32_t mem) {
+  return pfb::abi_guard([&]() -> int {
   if (!h || (n > 0 && !iq) || mem > PFB_MEM_DEVICE) return PFB_ERR_BAD_ARG;
   if (n == 0) return PFB_OK;
   DeviceGuard g(h->device);
@@ -836,9 +942,91 @@ int pfb_prime(pfb_handle* h, const void* iq, uint64_t n, uint32_t mem) {
   h->frame_index += f;
   if (mem == PFB_MEM_HOST) HIP_TRY(hipStreamSynchronize(h->stream));
   return PFB_OK;
+  });
+}
+
+uint64_t pfb_halo_samples(const pfb_handle* h) { return h ? (uint64_t)(h->M * h->P - 1 - h->off) : 0; }
+
+uint64_t pfb_shard_head_frames(const pfb_handle* h) {
+  return h ? (uint64_t)((h->hist_samples + h->D - 1) / h->D) : 0;
+}
+
+void* pfb_halo_recv_buffer(pfb_handle* h) {
+  if (!h || !h->d_halo) return nullptr;
+  return static_cast<char*>(h->d_halo) + ((size_t)h->hist_samples - (size_t)pfb_halo_samples(h)) * h->bps;
+}
+
+int pfb_shard_attach(pfb_handle* h, const pfb_shard_config* cfg) {
+  return pfb::abi_guard([&]() -> int {
+  if (!h || !cfg || cfg->struct_size != sizeof(pfb_shard_config)) return PFB_ERR_BAD_ARG;
+  if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) return PFB_ERR_BAD_ARG;
+  if (cfg->world > 1 && !cfg->exchange) return PFB_ERR_BAD_ARG;
+  DeviceGuard g(h->device);
+  if (!h->d_halo) {
+    // sized like the history so the kernels index it the same way; only its last pfb_halo_samples() are ever read
+    const size_t bytes = (size_t)h->hist_samples * h->bps;
+    HIP_TRY(hipMalloc(&h->d_halo, bytes));
+    HIP_TRY(hipMemset(h->d_halo, 0, bytes));
+    HIP_TRY(hipStreamCreateWithFlags(&h->s_halo, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_seg, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming));
+  }
+  h->shard_rank = cfg->rank;
+  h->shard_world = cfg->world;
+  h->shard_ring = cfg->ring != 0;
+  h->shard_exchange = cfg->exchange;
+  h->shard_user = cfg->user;
+  return PFB_OK;
+  });
+}
+
+int pfb_process_shard_async(pfb_handle* h, const void* d_seg, uint64_t n, void* d_out, uint64_t cap, uint64_t* frames_out) {
+  return pfb::abi_guard([&]() -> int {
+  if (!h || !d_seg) return PFB_ERR_BAD_ARG;
+  // a shard is cut on frame boundaries: whole frames in, no carried tail before or after
+  if (h->phase != 0 || n % (uint64_t)h->D != 0) return PFB_ERR_BAD_ARG;
+  const uint64_t F = n / (uint64_t)h->D, head = pfb_shard_head_frames(h);
+  if (frames_out) *frames_out = F;
+  if (F <= head) return PFB_ERR_BAD_ARG;  // the segment must at least hold its own head frames' windows
+  if (F > cap) return PFB_ERR_CAPACITY;
+  if (!d_out) return PFB_ERR_BAD_ARG;
+  DeviceGuard g(h->device);
+  const int world = h->shard_world, rank = h->shard_rank;
+  const bool receiving = world > 1 && (h->shard_ring || rank > 0);
+  const bool sending = world > 1 && (h->shard_ring || rank + 1 < world);
+  const size_t halo_bytes = (size_t)pfb_halo_samples(h) * h->bps;
+  if (sending || receiving) {
+    // side stream: the exchange starts once everything queued so far on the handle's stream (the caller's writes of
+    // the segment, the previous call's head frames that still read the landing zone) has finished
+    HIP_TRY(hipEventRecord(h->ev_seg, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->s_halo, h->ev_seg, 0));
+    const char* tail = static_cast<const char*>(d_seg) + (size_t)n * h->bps - halo_bytes;
+    const int crc = h->shard_exchange(h->shard_user, sending ? tail : nullptr, receiving ? pfb_halo_recv_buffer(h) : nullptr,
+                                      halo_bytes, sending ? (rank + 1) % world : -1,
+                                      receiving ? (rank + world - 1) % world : -1, h->s_halo);
+    if (crc != 0) {
+      char buf[96];
+      std::snprintf(buf, sizeof(buf), "halo exchange callback returned %d", crc);
+      g_detail = buf;
+      return PFB_ERR_COMM;
+    }
+    HIP_TRY(hipEventRecord(h->ev_halo, h->s_halo));
+  }
+  // main stream: every frame whose window lies inside the segment starts now ...
+  int rc = launch_frames(h, d_seg, n, nullptr, d_out, head, F, (int64_t)F, 0);
+  if (rc != PFB_OK) return rc;
+  // ... the head frames once the halo has landed (a wait on the GPU, not on the host); a shard that receives
+  // nothing continues from the handle's own state.  Waiting for the event also puts the SEND in front of
+  // whatever the caller queues next on this stream, so pfb_sync() covers both transfers.
+  if (sending || receiving) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo, 0));
+  rc = launch_frames(h, d_seg, n, receiving ? h->d_halo : h->d_hist[h->cur], d_out, 0, head, (int64_t)F, 0);
+  if (rc != PFB_OK) return rc;
+  return advance_state(h, d_seg, n, F);
+  });
 }
 
 int pfb_get_state(pfb_handle* h, void* buf, size_t* bytes) {
+  return pfb::abi_guard([&]() -> int {
   if (!h || !bytes) return PFB_ERR_BAD_ARG;
   const size_t hist_bytes = (size_t)h->hist_samples * h->bps;
   const size_t need = sizeof(StateHeader) + hist_bytes;
@@ -853,9 +1041,11 @@ int pfb_get_state(pfb_handle* h, void* buf, size_t* bytes) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   *bytes = need;
   return PFB_OK;
+  });
 }
 
 int pfb_set_state(pfb_handle* h, const void* buf, size_t bytes) {
+  return pfb::abi_guard([&]() -> int {
   if (!h || !buf || bytes < sizeof(StateHeader)) return PFB_ERR_BAD_ARG;
   StateHeader sh;
   std::memcpy(&sh, buf, sizeof(sh));
@@ -871,6 +1061,7 @@ int pfb_set_state(pfb_handle* h, const void* buf, size_t bytes) {
   h->phase = sh.phase;
   h->frame_index = sh.frame_index;
   return PFB_OK;
+  });
 }
 
 int pfb_set_frame_index(pfb_handle* h, uint64_t next_frame) {
@@ -886,6 +1077,7 @@ int pfb_get_frame_index(const pfb_handle* h, uint64_t* next_frame) {
 }
 
 int pfb_set_option(pfb_handle* h, int option, int64_t value) {
+  return pfb::abi_guard([&]() -> int {
   if (!h) return PFB_ERR_BAD_ARG;
   switch (option) {
     case PFB_OPT_KERNEL:
@@ -960,11 +1152,13 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
     default:
       return PFB_ERR_BAD_ARG;
   }
+  });
 }
 
 const char* pfb_last_kernel(const pfb_handle* h) { return h ? h->last_kernel : ""; }
 
 int pfb_get_kernel_times(pfb_handle* h, float* ms_out, int capacity, int* count) {
+  return pfb::abi_guard([&]() -> int {
   if (!h || !count || (capacity > 0 && !ms_out)) return PFB_ERR_BAD_ARG;
   DeviceGuard g(h->device);
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -974,6 +1168,7 @@ int pfb_get_kernel_times(pfb_handle* h, float* ms_out, int capacity, int* count)
   h->ev_used = 0;
   *count = n;
   return PFB_OK;
+  });
 }
 
 void* pfb_host_alloc(size_t bytes) {
@@ -990,7 +1185,8 @@ void pfb_host_free(void* p) {
 }
 
 int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double* bytes_per_sec) {
-  if (!bytes_per_sec || iters < 1 || bytes_in < 16) return PFB_ERR_BAD_ARG;
+  return pfb::abi_guard([&]() -> int {
+  if (!bytes_per_sec || iters < 1 || bytes_in < 512) return PFB_ERR_BAD_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -999,7 +1195,7 @@ int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double*
   int dev = device_id;
   if (dev < 0) HIP_TRY(hipGetDevice(&dev));
   DeviceGuard g(dev);
-  const long long nvec = (long long)(bytes_in / 16);
+  const long long nvec = (long long)(bytes_in / 512) * 32;  // whole row pairs (512 bytes of input per wave)
   void *in = nullptr, *out = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = PFB_OK;
@@ -1022,6 +1218,7 @@ int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double*
   (void)hipFree(in);
   (void)hipFree(out);
   return rc;
+  });
 }
 
 }  // extern "C"

@@ -4,9 +4,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <new>
+
 #include "pfb_channelizer.h"
 
 namespace pfb {
+
+// Every extern "C" entry point that can allocate host memory, build a std::string / std::vector, take a mutex
+// or start a thread runs its body under this guard: the header promises "never throws", and an exception
+// unwinding through a C caller (the recorders' loop, MATLAB's loadlibrary, ctypes) is undefined behaviour.
+template <class F>
+static inline int abi_guard(F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return PFB_ERR_NO_MEMORY;
+  } catch (...) {
+    return PFB_ERR_INTERNAL;
+  }
+}
 
 // Kernel-side view of one pfb_process call.  "Row r" is the D input samples
 // whose newest member is the newest sample of local frame r:

@@ -217,19 +217,25 @@ hipError_t launch_transpose_slab(const void* slab, long long frames, int M, void
 }
 
 // ---------------------------------------------------------------------------------
-// 1 read : 2 write streaming copy (same byte mix as int16 -> complex64, D = M)
+// 1 read : 2 write streaming copy (same byte mix as int16 -> complex64, D = M): the yardstick next to the
+// nominal roofline.  The shape is the fastest of tools/membench2's sweep on MI355X (profiles/r01_membench2_patterns.txt,
+// 6.2 TB/s): short-lived 4-wave workgroups in dispatch order, each wave reading two 256-byte rows (one dword per lane
+// and row) and writing them back as ONE 16-byte store per lane (1 KB per wave instruction) -- DRAM rows are finished
+// while they are open.  A grid-stride loop over the same bytes (what this was in round 1) reaches 4.7 TB/s.
 
-__global__ void __launch_bounds__(256) pfb_stream_copy_kernel(const uint4* in, uint4* out, long long n) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint4 v = in[i];
-    out[i] = v;
-    out[n + i] = v;
-  }
+__global__ void __launch_bounds__(256) pfb_stream_copy_kernel(const unsigned* in, uint4* out, long long row_pairs) {
+  const long long pair = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= row_pairs) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned a = in[pair * 128 + lane], b = in[pair * 128 + 64 + lane];
+  out[pair * 64 + lane] = make_uint4(a, a + 1u, b, b + 1u);
 }
 
 hipError_t launch_stream_copy(const void* in, void* out, long long n_vec16, hipStream_t s) {
-  hipLaunchKernelGGL(pfb_stream_copy_kernel, dim3(256 * 8), dim3(256), 0, s, (const uint4*)in, (uint4*)out, n_vec16);
+  const long long row_pairs = n_vec16 / 32;  // 512 bytes of input per wave
+  if (row_pairs <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pfb_stream_copy_kernel, dim3((unsigned)((row_pairs + 3) / 4)), dim3(256), 0, s, (const unsigned*)in,
+                     (uint4*)out, row_pairs);
   return hipGetLastError();
 }
 

@@ -30,12 +30,7 @@
 #include <string>
 #include <vector>
 
-#include "pfb_channelizer.h"
-
-namespace pfb {  // pfb_kernels.hip
-hipError_t launch_transpose_slab(const void* slab, long long frames, int M, void* out, long long out_ld,
-                                 long long out_frame0, int elem_bytes, hipStream_t s);
-}
+#include "pfb_common.h"  // abi_guard, launch_transpose_slab (pfb_kernels.hip)
 
 namespace {
 
@@ -900,9 +895,11 @@ __global__ void __launch_bounds__(256) pdw_pulse_kernel(Src src, int M, const lo
     o.toa = ((double)(toa + 1) / fs) + t0;            // :98 / :67 (1-based index)
     o.snr = 10.0 * log10(amp / nf[b]);                // :105 / :74
     o.pw = (double)(jj - toa) / fs;                   // :110 / :79
-    // :80 indexes the UNSHIFTED centre-frequency list with the shifted column; the raw script has no bins
+    // :80 binFreqs(bin), bin = column of the fftshift-ed matrix: the column's true centre frequency, or -- with
+    // PFB_PDW_BINFREQ_UNSHIFTED -- the FFT-ordered list indexed by the shifted column (what the script computes if
+    // MathWorks' centerFrequencies returns the unshifted list; unpinned).  bin_freqs is FFT-ordered; the raw script has no bins
     const double fbin = !bin_freqs ? 0.0
-                        : (flags & PFB_PDW_MATLAB_QUIRKS) ? bin_freqs[b] : bin_freqs[(b + (M + 1) / 2) % M];
+                        : (flags & PFB_PDW_BINFREQ_UNSHIFTED) ? bin_freqs[b] : bin_freqs[(b + (M + 1) / 2) % M];
     o.freq = (fc + fbin) + (fs / (360.0 / med));      // :122 / :91
     o.sat = sat_flag;
     o.bin = b;
@@ -1058,6 +1055,7 @@ extern "C" const char* pfb_pdw_last_error_detail(void) { return g_pdw_detail.c_s
 extern "C" int pfb_pdw_last_noise_floor_path(void) { return g_pdw_path; }
 
 extern "C" int pfb_pdw_release_workspace(int32_t device_id) {
+  return pfb::abi_guard([&] {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   int prev = -1;
   (void)hipGetDevice(&prev);
@@ -1072,7 +1070,8 @@ extern "C" int pfb_pdw_release_workspace(int32_t device_id) {
   }
   if (prev >= 0) (void)hipSetDevice(prev);
   (void)hipGetLastError();
-  return PFB_OK;
+  return (int)PFB_OK;
+  });
 }
 
 // host twin of dkey_inv (the raw cf32 noise floor is finished on the host)
@@ -1211,10 +1210,10 @@ struct DeviceScope {
 
 }  // namespace
 
-extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, uint32_t decimation, double fs_in,
-                               double fc, double sample_start_time, double snr_threshold_db, uint32_t flags,
-                               pfb_pdw* out, uint64_t capacity, uint64_t* count, double* noise_floor_out, uint32_t mem,
-                               int32_t device_id, void* hip_stream) {
+static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint32_t decimation, double fs_in,
+                            double fc, double sample_start_time, double snr_threshold_db, uint32_t flags,
+                            pfb_pdw* out, uint64_t capacity, uint64_t* count, double* noise_floor_out, uint32_t mem,
+                            int32_t device_id, void* hip_stream) {
   if (!y_in || !count || M < 1 || decimation < 1 || frames < 1 || mem > PFB_MEM_DEVICE || (capacity && !out))
     return PFB_ERR_BAD_ARG;
   int ndev = 0;
@@ -1390,6 +1389,17 @@ done:
   return rc;
 }
 
+// nothing thrown (std::vector / std::string / std::mutex inside the implementation) crosses the C ABI
+extern "C" int pfb_pdw_extract(const void* y_in, uint64_t frames, uint32_t M, uint32_t decimation, double fs_in,
+                               double fc, double sample_start_time, double snr_threshold_db, uint32_t flags,
+                               pfb_pdw* out, uint64_t capacity, uint64_t* count, double* noise_floor_out, uint32_t mem,
+                               int32_t device_id, void* hip_stream) {
+  return pfb::abi_guard([&] {
+    return pdw_extract_impl(y_in, frames, M, decimation, fs_in, fc, sample_start_time, snr_threshold_db, flags, out, capacity,
+                            count, noise_floor_out, mem, device_id, hip_stream);
+  });
+}
+
 // ---- raw stream (matlab/create_pdws.m:30-105) -------------------------------------------------------
 
 namespace {
@@ -1474,10 +1484,10 @@ done:
 
 }  // namespace
 
-extern "C" int pfb_pdw_extract_raw(const void* iq, uint64_t num_samples, uint32_t sample_format, uint32_t bit_width,
-                                   double fs, double fc, double sample_start_time, double snr_threshold_db,
-                                   double trailing_threshold_db, pfb_pdw* out, uint64_t capacity, uint64_t* count,
-                                   double* noise_floor_out, uint32_t mem, int32_t device_id, void* hip_stream) {
+static int pdw_extract_raw_impl(const void* iq, uint64_t num_samples, uint32_t sample_format, uint32_t bit_width,
+                                double fs, double fc, double sample_start_time, double snr_threshold_db,
+                                double trailing_threshold_db, pfb_pdw* out, uint64_t capacity, uint64_t* count,
+                                double* noise_floor_out, uint32_t mem, int32_t device_id, void* hip_stream) {
   if (!iq || !count || num_samples < 2 || sample_format > PFB_FMT_CF32 || mem > PFB_MEM_DEVICE || (capacity && !out))
     return PFB_ERR_BAD_ARG;
   if (sample_format != PFB_FMT_CF32 && (bit_width < 1 || bit_width > 16)) return PFB_ERR_BAD_ARG;
@@ -1534,4 +1544,14 @@ extern "C" int pfb_pdw_extract_raw(const void* iq, uint64_t num_samples, uint32_
 done:
   (void)hipStreamSynchronize(st);
   return rc;
+}
+
+extern "C" int pfb_pdw_extract_raw(const void* iq, uint64_t num_samples, uint32_t sample_format, uint32_t bit_width,
+                                   double fs, double fc, double sample_start_time, double snr_threshold_db,
+                                   double trailing_threshold_db, pfb_pdw* out, uint64_t capacity, uint64_t* count,
+                                   double* noise_floor_out, uint32_t mem, int32_t device_id, void* hip_stream) {
+  return pfb::abi_guard([&] {
+    return pdw_extract_raw_impl(iq, num_samples, sample_format, bit_width, fs, fc, sample_start_time, snr_threshold_db,
+                                trailing_threshold_db, out, capacity, count, noise_floor_out, mem, device_id, hip_stream);
+  });
 }

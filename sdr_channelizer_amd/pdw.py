@@ -17,11 +17,18 @@ PDW_DTYPE = np.dtype([("toa", "f8"), ("freq", "f8"), ("pw", "f8"), ("snr", "f8")
 
 def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decimation: int | None = None,
                  snr_threshold_db: float = 15.0, matlab_quirks: bool = True, capacity: int = 1 << 20,
-                 return_noise_floor: bool = False, device: int = -1, channel_major: bool = False):
+                 return_noise_floor: bool = False, device: int = -1, channel_major: bool = False,
+                 binfreq_unshifted: bool = False):
     """y: (frames, M) complex64, frame-major, fftshift-ed -- a numpy array or a torch CUDA tensor
     (used in place); with channel_major=True y is (M, frames), MATLAB's own layout of the same matrix (what a
     channel-major Channelizer returns).  Returns a structured numpy array with PDW_DTYPE, in the reference's order
-    (channels outermost, time within a channel)."""
+    (channels outermost, time within a channel).
+
+    matlab_quirks: the script's phase(toa:jj) at :114 linear-indexes column 1 whatever channel the pulse is in
+    (reference behaviour, default on).  binfreq_unshifted: take fc_chan (:80) from the FFT-ordered centre-frequency list
+    indexed with the shifted column -- what the script computes IF MathWorks' centerFrequencies returns the unshifted
+    list; that order is not pinned (closed toolbox; channelizer_example.m:58-66 suggests the list is centred), so the
+    default is the column's true centre frequency."""
     lib = L.load()
     is_torch = type(y).__module__.startswith("torch")
     if is_torch and y.is_cuda:
@@ -40,7 +47,8 @@ def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decima
     assert out.dtype.itemsize == C.sizeof(L.PfbPdw)
     nf = np.zeros(M, dtype=np.float64)
     count = C.c_uint64(0)
-    flags = (L.PFB_PDW_MATLAB_QUIRKS if matlab_quirks else 0) | (L.PFB_PDW_CHANNEL_MAJOR if channel_major else 0)
+    flags = (L.PFB_PDW_MATLAB_QUIRKS if matlab_quirks else 0) | (L.PFB_PDW_CHANNEL_MAJOR if channel_major else 0) \
+        | (L.PFB_PDW_BINFREQ_UNSHIFTED if binfreq_unshifted else 0)
     rc = lib.pfb_pdw_extract(ptr, frames, M, M if decimation is None else int(decimation), float(fs_in), float(fc),
                              float(sample_start_time), float(snr_threshold_db), flags,
                              out.ctypes.data_as(C.POINTER(L.PfbPdw)), capacity, C.byref(count),
@@ -56,7 +64,8 @@ def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decima
 
 
 def pdws_from_iq_file(channelizer, path: str, *, snr_threshold_db: float = 15.0, matlab_quirks: bool = True,
-                      capacity: int = 1 << 20, reset: bool = True, return_noise_floor: bool = False):
+                      capacity: int = 1 << 20, reset: bool = True, return_noise_floor: bool = False,
+                      binfreq_unshifted: bool = False):
     """One iteration of create_pdws_channelized.m:22-143 in one call (pfb_pdw_from_iq_file): the record at ``path``
     is streamed through ``channelizer`` (a frame-major, complex-output Channelizer matching the record), the channel
     matrix stays on the GPU, the PDWs come back.  fs, fc and the start time are the record's.  Returns (pdws, info)
@@ -69,7 +78,9 @@ def pdws_from_iq_file(channelizer, path: str, *, snr_threshold_db: float = 15.0,
     count = C.c_uint64(0)
     info = L.PfbIqInfo()
     rc = lib.pfb_pdw_from_iq_file(channelizer._h, path.encode(), float(snr_threshold_db),
-                                  L.PFB_PDW_MATLAB_QUIRKS if matlab_quirks else 0, out.ctypes.data_as(C.POINTER(L.PfbPdw)),
+                                  (L.PFB_PDW_MATLAB_QUIRKS if matlab_quirks else 0)
+                                  | (L.PFB_PDW_BINFREQ_UNSHIFTED if binfreq_unshifted else 0),
+                                  out.ctypes.data_as(C.POINTER(L.PfbPdw)),
                                   capacity, C.byref(count), nf.ctypes.data_as(C.POINTER(C.c_double)), C.byref(info))
     if rc != L.PFB_OK:
         detail = lib.pfb_pdw_last_error_detail().decode()

@@ -28,14 +28,54 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pfb_abi_version() == 1
+    assert lib.pfb_abi_version() == L.PFB_ABI_VERSION == 2
 
 
 def test_strerror_and_center_frequencies(oracle):
     lib = L.load()
     assert lib.pfb_strerror(0) == b"ok" and lib.pfb_strerror(L.PFB_ERR_NO_DEVICE) == b"no HIP device"
+    assert lib.pfb_strerror(L.PFB_ERR_INTERNAL).startswith(b"internal") and lib.pfb_strerror(L.PFB_ERR_COMM).startswith(b"halo")
     for M, fs in ((8, 8e6), (56, 56e6), (5, 5.0)):
-        assert np.array_equal(pkg.center_frequencies(M, fs), oracle.center_frequencies(M, fs))
+        fft = pkg.center_frequencies(M, fs)
+        assert np.array_equal(fft, oracle.center_frequencies(M, fs))
+        # centred order = the frequency of every column of fftshift(out, 2): ascending from -floor(M/2) * fs / M
+        centered = pkg.center_frequencies(M, fs, order="centered")
+        assert np.array_equal(centered, np.fft.fftshift(fft)) and np.all(np.diff(centered) > 0)
+    out = np.zeros(4)
+    assert lib.pfb_center_frequencies_ordered(4, 1.0, 2, out.ctypes.data_as(C.POINTER(C.c_double))) == L.PFB_ERR_BAD_ARG
+
+
+def test_nothing_thrown_crosses_the_c_abi():
+    """Every entry point that can allocate or throw runs under one guard (pfb_common.h, abi_guard); the diagnostic entry
+    throws inside that same guard: bad_alloc -> PFB_ERR_NO_MEMORY, anything else -> PFB_ERR_INTERNAL, never an
+    exception unwinding into the (C / ctypes / MATLAB) caller."""
+    lib = L.load()
+    assert lib.pfb_selftest_exception_guard(0) == L.PFB_ERR_NO_MEMORY
+    assert lib.pfb_selftest_exception_guard(1) == L.PFB_ERR_INTERNAL
+    assert lib.pfb_selftest_exception_guard(2) == L.PFB_ERR_INTERNAL
+    assert lib.pfb_selftest_exception_guard(3) == L.PFB_OK
+    # and every extern "C" definition in the product sources that builds C++ objects sits under the guard
+    csrc = os.path.join(ROOT, "sdr_channelizer_amd", "csrc")
+    api = open(os.path.join(csrc, "pfb_api.cpp")).read()
+    for name in ("pfb_create", "pfb_process", "pfb_process_async", "pfb_process_iq_file", "pfb_pdw_from_iq_file",
+                 "pfb_pdw_raw_from_iq_file", "pfb_prime", "pfb_set_option", "pfb_get_kernel_times", "pfb_shard_attach",
+                 "pfb_process_shard_async"):
+        body = api[api.index(f"\nint {name}("):]
+        assert "abi_guard" in body[: body.index("\n}\n")].split("{", 1)[1][:80], name
+    pdw = open(os.path.join(csrc, "pfb_pdw.hip")).read()
+    for name in ("pfb_pdw_extract", "pfb_pdw_extract_raw", "pfb_pdw_release_workspace"):
+        body = pdw[pdw.index(f'extern "C" int {name}('):]
+        assert "abi_guard" in body[: body.index("\n}\n")], name
+
+
+def test_shard_entry_points_validate_arguments():
+    lib = L.load()
+    cfg = L.PfbShardConfig(C.sizeof(L.PfbShardConfig), 0, 2, 0, L.HALO_EXCHANGE_FN(0), None)
+    assert lib.pfb_shard_attach(None, C.byref(cfg)) == L.PFB_ERR_BAD_ARG
+    assert lib.pfb_halo_samples(None) == 0 and lib.pfb_shard_head_frames(None) == 0
+    assert lib.pfb_halo_recv_buffer(None) is None
+    n = C.c_uint64()
+    assert lib.pfb_process_shard_async(None, None, 0, None, 0, C.byref(n)) == L.PFB_ERR_BAD_ARG
 
 
 def test_prototype_matches_oracle_design(oracle):

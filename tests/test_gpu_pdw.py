@@ -65,12 +65,14 @@ def synthetic_matrix(F=6000, M=16, seed=0):
     return y.astype(np.complex64)
 
 
-@pytest.mark.parametrize("quirks", [True, False])
-def test_synthetic_pulses_match_oracle(oracle, quirks):
+@pytest.mark.parametrize("quirks,unshifted", [(True, False), (False, False), (True, True), (False, True)])
+def test_synthetic_pulses_match_oracle(oracle, quirks, unshifted):
+    """quirks = the :114 column-1 phase indexing; unshifted = binFreqs as an FFT-ordered list (:42/:80, unpinned)"""
     y = synthetic_matrix()
     fs_in, fc, t0 = 16e6, 2.4e9, 1.7e9
-    got, nf = extract_pdws(y, fs_in, fc, t0, matlab_quirks=quirks, return_noise_floor=True)
-    want = oracle.extract_pdws(y.astype(np.complex128), fs_in, fc, t0, 15.0, matlab_quirks=quirks)
+    got, nf = extract_pdws(y, fs_in, fc, t0, matlab_quirks=quirks, binfreq_unshifted=unshifted, return_noise_floor=True)
+    want = oracle.extract_pdws(y.astype(np.complex128), fs_in, fc, t0, 15.0, matlab_quirks=quirks,
+                               binfreq_unshifted=unshifted)
     compare(got, want, fs_in / y.shape[1])
     mag = np.abs(y.astype(np.complex128))
     assert np.allclose(nf, np.median(mag, axis=0), rtol=1e-12, atol=0)

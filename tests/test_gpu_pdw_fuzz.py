@@ -38,10 +38,12 @@ def test_channelized_pdws_random(oracle, case):
         y = np.round(y.real * g) / g + 1j * np.round(y.imag * g) / g
     y = y.astype(np.complex64)
     snr = float(rng.choice([6.0, 10.0, 15.0, 20.0]))
-    quirks = bool(rng.integers(2))
+    quirks, unshifted = bool(rng.integers(2)), bool(rng.integers(2))
     fs_in, fc, t0 = 56e6, 915e6, float(rng.uniform(0, 2e9))
-    got, nf = extract_pdws(y, fs_in, fc, t0, snr_threshold_db=snr, matlab_quirks=quirks, return_noise_floor=True)
-    want = oracle.extract_pdws(y.astype(np.complex128), fs_in, fc, t0, snr, matlab_quirks=quirks, max_out=1 << 18)
+    got, nf = extract_pdws(y, fs_in, fc, t0, snr_threshold_db=snr, matlab_quirks=quirks, binfreq_unshifted=unshifted,
+                           return_noise_floor=True)
+    want = oracle.extract_pdws(y.astype(np.complex128), fs_in, fc, t0, snr, matlab_quirks=quirks, max_out=1 << 18,
+                               binfreq_unshifted=unshifted)
     assert np.allclose(nf, np.median(np.abs(y.astype(np.complex128)), axis=0), rtol=1e-12, atol=0)
 
     def phase_col(i):  # the samples pulse i spans, located with t0 = 0 (toa + t0 has no sample resolution left)

@@ -1,0 +1,260 @@
+"""The product's time-shard path on the GPU, through the C ABI (pfb_shard_attach / pfb_process_shard_async):
+sharded == single stream, bit for bit.
+
+* one device, G handles, the halo moved by a callback that is a plain device-to-device copy on the side stream the
+  library hands over -- everything but the transport is the real thing: halo of M*P-1-input_offset samples, interior
+  frames first, head frames behind the event, ring and open chains, oversampled banks whose halo is not a whole
+  number of frames;
+* two devices over the nccl backend (RCCL), one process per GPU, skipped when the box has fewer than two GPUs."""
+import ctypes as C
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from sdr_channelizer_amd import Channelizer, synth  # noqa: E402
+from sdr_channelizer_amd import _lib as L  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_hip = None
+
+
+def hip_memcpy_async(dst, src, nbytes, stream):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")  # the runtime torch already loaded
+        _hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    rc = _hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), nbytes, 3, C.c_void_p(stream))  # 3 = device to device
+    assert rc == 0, rc
+
+
+class Mailbox:
+    """Single-process stand-in for the transport: rank r's send parks its tail in slot r (a copy on the side stream, so
+    the sender's segment may change afterwards); rank r+1's receive copies slot r into the landing zone."""
+
+    def __init__(self, world, nbytes):
+        import torch
+        self.slots = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(world)]
+        self.calls = []
+
+    def exchange_for(self, rank):
+        def exchange(d_send, d_recv, nbytes, send_to, recv_from, stream):
+            import torch
+            self.calls.append((rank, bool(d_send), bool(d_recv), nbytes, send_to, recv_from))
+            if recv_from >= 0:  # ranks run in order here, so the predecessor's tail is already parked
+                assert d_recv
+                hip_memcpy_async(d_recv, self.slots[recv_from].data_ptr(), nbytes, stream)
+            if send_to >= 0:
+                assert d_send
+                hip_memcpy_async(self.slots[rank].data_ptr(), d_send, nbytes, stream)
+                torch.cuda.synchronize()  # the next rank's receive runs on another stream: park the tail first
+            return 0
+        return exchange
+
+
+@pytest.mark.parametrize("M,P,D,fmt,bw,kw", [
+    (64, 12, 64, "int16", 12, {}),                                   # cfg2
+    (64, 12, 64, "int16", 12, dict(channel_major=True)),
+    (128, 12, 64, "int16", 12, dict(derotate=True)),                 # cfg5: 2x oversampled, frame index matters
+    (256, 8, 256, "int8", 8, dict(fftshift=True)),                   # cfg3
+    (1024, 16, 1024, "int16", 16, {}),                               # cfg4: the team kernel
+    (1024, 16, 1024, "int16", 16, dict(channel_major=True)),         # by slabs
+    (56, 12, 56, "int16", 12, {}),
+    (16, 4, 8, "int16", 12, {}),                                     # generic kernel, oversampled
+    (12, 3, 5, "int16", 12, dict(input_offset=2)),                   # D does not divide M*P: the halo (33) is no whole number of frames
+])
+def test_sharded_handles_equal_single_stream_bit_exact(M, P, D, fmt, bw, kw):
+    import torch
+    G = 3
+    seg_frames = 700 if M < 1024 else 90
+    n = G * seg_frames * D
+    iq = synth.pulsed_iq_numpy(n, bw, np.int8 if fmt == "int8" else np.int16, seed=M + D)
+    h = np.random.default_rng(4).standard_normal(M * P).astype(np.float32)
+    cm = kw.get("channel_major", False)
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, **kw) as ch:
+        one = ch(iq)
+        halo = ch.halo_samples
+        assert halo == M * P - 1 - (kw.get("input_offset", D - 1))
+        if D == M and "input_offset" not in kw:
+            assert halo == (P - 1) * M  # north star: the (taps_per_branch - 1) * M overlap samples only
+    d_iq = torch.from_numpy(iq).cuda()
+    box = Mailbox(G, halo * (2 if fmt == "int8" else 4))
+    outs = []
+    for g in range(G):  # one handle per shard, as on G devices
+        with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, **kw) as sh:
+            sh.attach_shard(g, G, box.exchange_for(g), ring=False)
+            sh.set_frame_index(g * seg_frames)
+            y = sh.process_shard(d_iq[g * seg_frames * D:(g + 1) * seg_frames * D])
+            sh.sync()
+            outs.append(y.cpu().numpy())
+    got = np.concatenate(outs, axis=1 if cm else 0)
+    assert got.shape == one.shape and np.array_equal(got, one)
+    # open chain: rank 0 receives nothing, the last rank sends nothing; everyone else both
+    assert [(c[0], c[1], c[2]) for c in box.calls] == [(0, True, False), (1, True, True), (2, False, True)]
+
+
+def test_ring_shard_continues_the_previous_batch_and_updates_state():
+    """ring=True (what bench.py times): rank 0's halo is the last rank's tail of the batch before, so batch after batch
+    is one endless stream; and after a shard call the handle's own state is the segment's tail, as after pfb_process."""
+    import torch
+    M, P, D, G, F = 64, 12, 64, 2, 500
+    h = np.random.default_rng(9).standard_normal(M * P).astype(np.float32)
+    iq = synth.pulsed_iq_numpy(2 * G * F * D, 12, np.int16, seed=3)  # two batches of G segments
+    with Channelizer(M, taps=h, bit_width=12) as ch:
+        one = ch(iq)
+    d_iq = torch.from_numpy(iq).cuda()
+    box = Mailbox(G, (P - 1) * M * 4)
+    hs = [Channelizer(M, taps=h, bit_width=12) for _ in range(G)]
+    try:
+        for g in range(G):
+            hs[g].attach_shard(g, G, box.exchange_for(g), ring=True)
+        rows = []
+        for batch in range(2):
+            for g in range(G):
+                s = (batch * G + g) * F * D
+                rows.append(hs[g].process_shard(d_iq[s:s + F * D]))
+                hs[g].sync()
+        got = torch.cat(rows).cpu().numpy()
+        # the very first segment received the (zero) parked slot of the last rank = stream start; everything after
+        # continues bit-exactly across segment AND batch boundaries
+        assert np.array_equal(got, one)
+        # state after a shard call = the segment's tail: a plain call continues the stream
+        tail_in = synth.pulsed_iq_numpy(D * 40, 12, np.int16, seed=77)
+        with Channelizer(M, taps=h, bit_width=12) as ref:
+            ref(iq[: (G + G) * F * D])  # same history as hs[G-1] now has
+            want = ref(tail_in)
+        assert np.array_equal(hs[G - 1](tail_in), want)
+    finally:
+        for x in hs:
+            x.release()
+
+
+def test_shard_call_rejects_what_it_cannot_shard():
+    import torch
+    M, P = 64, 12
+    h = np.zeros(M * P, np.float32)
+    with Channelizer(M, taps=h, bit_width=12) as ch:
+        ch.attach_shard(0, 1)
+        short = torch.zeros((ch.shard_head_frames * M, 2), dtype=torch.int16, device="cuda")
+        with pytest.raises(L.PfbError):   # a segment must be longer than its head frames
+            ch.process_shard(short)
+        with pytest.raises(ValueError):   # whole frames only
+            ch.process_shard(torch.zeros((M * 100 + 1, 2), dtype=torch.int16, device="cuda"))
+        ch(np.zeros((7, 2), np.int16))    # a carried tail: no longer on a frame boundary
+        with pytest.raises(L.PfbError):
+            ch.process_shard(torch.zeros((M * 100, 2), dtype=torch.int16, device="cuda"))
+
+        def failing(*a):
+            return 7
+        ch.reset()
+        ch.attach_shard(0, 2, failing, ring=True)
+        with pytest.raises(L.PfbError) as e:
+            ch.process_shard(torch.zeros((M * 100, 2), dtype=torch.int16, device="cuda"))
+        assert e.value.status == L.PFB_ERR_COMM
+
+
+def test_tensor_arguments_are_validated_before_they_reach_the_library():
+    import torch
+    M, P = 64, 12
+    h = np.zeros(M * P, np.float32)
+    with Channelizer(M, taps=h, bit_width=12) as ch:  # an int16 handle
+        with pytest.raises(TypeError):
+            ch(torch.zeros((M * 10, 2), dtype=torch.int8, device="cuda"))     # would be read 2x past its end
+        with pytest.raises(TypeError):
+            ch.prime(torch.zeros((M * 10, 2), dtype=torch.float32, device="cuda"))
+        with pytest.raises(ValueError):
+            ch(torch.zeros((M * 10, 3), dtype=torch.int16, device="cuda"))     # not I,Q pairs
+        good = torch.zeros((M * 10, 2), dtype=torch.int16, device="cuda")
+        with pytest.raises(ValueError):
+            ch(good, out=torch.empty((5, M), dtype=torch.complex64, device="cuda"))   # too short
+        with pytest.raises(ValueError):
+            ch(good, out=torch.empty((10, M), dtype=torch.complex64))                 # host tensor for a device call
+        with pytest.raises(ValueError):
+            ch(np.zeros((M * 10, 2), np.int16), out=np.empty((5, M), np.complex64))   # host path: short numpy out
+        with pytest.raises(ValueError):
+            ch(np.zeros((M * 10, 2), np.int16), out=np.empty((10, M), np.complex128))
+        y = ch(np.zeros((M * 10, 2), np.int16), out=np.empty((10, M), np.complex64))
+        assert y.shape == (10, M)
+
+
+def test_counter_stream_on_the_gpu_equals_its_host_twin():
+    import torch
+    for bw, dt, tdt in ((12, np.int16, torch.int16), (8, np.int8, torch.int8)):
+        for start, n in ((0, 300_000), ((1 << 32) * 5 + 999, 100_000)):
+            a = synth.pulsed_iq_counter_numpy(n, bw, dt, start=start)
+            b = synth.pulsed_iq_torch(n, bw, tdt, device="cuda", start=start, chunk=1 << 17).cpu().numpy()
+            assert np.array_equal(a, b)
+
+
+_TWO_DEVICE_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from sdr_channelizer_amd import Channelizer, synth
+from sdr_channelizer_amd.sharded import ShardedChannelizer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+M, P, D, F = 64, 12, 64, 4096
+h = np.random.default_rng(1).standard_normal(M * P).astype(np.float32)
+seg = synth.pulsed_iq_torch(F * D, 12, torch.int16, device=torch.device("cuda", rank), start=rank * F * D)
+for mode in ("p2p", "allgather"):
+    with Channelizer(M, taps=h, bit_width=12, device=rank) as ch:
+        y = ShardedChannelizer(ch, rank, world, mode=mode).process_segment(seg, first_frame=rank * F)
+        np.save(os.path.join({out!r}, f"shard_{{mode}}_{{rank}}.npy"), y.cpu().numpy())
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(600)
+def test_two_devices_over_rccl_equal_one_device(tmp_path):
+    """The product on 2 GPUs, one process each, halo over the nccl backend (RCCL): bit-equal to one device."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU node)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(_TWO_DEVICE_WORKER.format(root=ROOT, out=str(tmp_path)))
+    procs = []
+    for r in range(2):  # fresh children: no process that touched the GPU is re-exec'd
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    assert [p.wait(timeout=500) for p in procs] == [0, 0]
+    M, P, D, F = 64, 12, 64, 4096
+    h = np.random.default_rng(1).standard_normal(M * P).astype(np.float32)
+    iq = synth.pulsed_iq_counter_numpy(2 * F * D, 12, np.int16)
+    with Channelizer(M, taps=h, bit_width=12, device=0) as ch:
+        one = ch(iq)
+    for mode in ("p2p", "allgather"):
+        got = np.concatenate([np.load(tmp_path / f"shard_{mode}_{r}.npy") for r in range(2)])
+        assert np.array_equal(got, one), mode
+
+
+def test_cpp_host_shards_over_every_gpu_with_rccl(tmp_path):
+    """examples/sharded_rccl.cpp: the C++ host a recorder loop becomes on a multi-GPU node -- a thread and a handle per
+    device, pfb_shard_attach with an ncclSend/ncclRecv callback, pfb_process_shard_async -- built with hipcc against
+    RCCL and run as its own process.  It checks itself against one device and exits non-zero on any difference.  On a
+    one-GPU box world = 1 and the exchange is skipped; the shard call (interior + head launches) still runs from C++."""
+    import shutil
+    from sdr_channelizer_amd import LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) or not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no hipcc / RCCL headers on this box")
+    exe = os.path.join(tmp_path, "sharded_rccl")
+    libdir = os.path.dirname(LIB_PATH)
+    subprocess.run([hipcc, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "sharded_rccl.cpp"), "-o", exe, "-L" + libdir, "-lpfb_channelizer",
+                    "-lrccl", "-Wl,-rpath," + libdir], check=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "8192"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bit-identical to one device" in r.stdout

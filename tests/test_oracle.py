@@ -179,9 +179,14 @@ def test_pdw_extraction_on_a_synthetic_pulse(oracle):
     want_f = fc + unshifted[(5 + M // 2) % M] + fs / (360.0 / dphi)
     assert abs(p["freq"] - want_f) < 0.05 * fs
     assert not p["sat"]
-    # the reference's own indexing quirks change freq, nothing else
+    # the reference's own indexing choices change freq, nothing else
     q = [p for p in oracle.extract_pdws(y, fs_in, fc, t0, 15.0, matlab_quirks=True) if p["bin"] == 5][0]
     assert q["toa"] == p["toa"] and q["pw"] == p["pw"] and q["snr"] == p["snr"]
+    # binFreqs as an FFT-ordered list indexed by the shifted column (:42 / :80 if centerFrequencies is unshifted):
+    # exactly half the band away from the column's true centre, everything else equal
+    u = [p for p in oracle.extract_pdws(y, fs_in, fc, t0, 15.0, matlab_quirks=False, binfreq_unshifted=True) if p["bin"] == 5][0]
+    assert abs((u["freq"] - p["freq"]) - (unshifted[5] - unshifted[(5 + M // 2) % M])) < 1e-6
+    assert u["toa"] == p["toa"] and u["pw"] == p["pw"] and u["snr"] == p["snr"]
 
 
 def test_raw_pdw_extraction_known_answer(oracle):

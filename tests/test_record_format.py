@@ -73,14 +73,29 @@ def test_bad_headers_are_rejected():
     info = L.PfbIqInfo()
     bad = np.array([0xdeadbeef] + [0] * 27, dtype="<u4").tobytes()
     assert lib.pfb_iq_parse_header(bad, len(bad), C.byref(info)) == L.PFB_ERR_BAD_FORMAT
-    big_endian = bytes(112)  # marker 0x00000000: convert_my_iq_to_mat.m:43 "big endian"; no writer emits it
-    assert lib.pfb_iq_parse_header(big_endian, 112, C.byref(info)) == L.PFB_ERR_BAD_FORMAT
+    all_zero = bytes(112)  # marker 0 is accepted as format 2 (below), but bitWidth 0 is not a sample format (:96-98)
+    assert lib.pfb_iq_parse_header(all_zero, 112, C.byref(info)) == L.PFB_ERR_BAD_FORMAT
     short = np.array([0x03030303], dtype="<u4").tobytes() + bytes(20)
     assert lib.pfb_iq_parse_header(short, len(short), C.byref(info)) == L.PFB_ERR_BAD_ARG
     hdr = bytearray(112)
     hdr[0:4] = (0x03030303).to_bytes(4, "little")
     hdr[32:36] = (24).to_bytes(4, "little")  # bitWidth 24: "Unsupported bit width" (:96-98)
     assert lib.pfb_iq_parse_header(bytes(hdr), 112, C.byref(info)) == L.PFB_ERR_BAD_FORMAT
+
+
+def test_marker_zero_reads_as_format_2_in_native_byte_order():
+    """convert_my_iq_to_mat.m:42-45: marker 0x00000000 prints "big endian", sets fileFormat = 2 -- and keeps reading with
+    the byte order the file was opened with (native), so the fields are those of a little-endian format-2 header."""
+    hdr = bytearray(112)
+    hdr[4:8] = (5000).to_bytes(4, "little")
+    hdr[8:16] = (2_412_000_000).to_bytes(8, "little")
+    hdr[20:24] = (56_000_000).to_bytes(4, "little")
+    hdr[28:32] = (1234).to_bytes(4, "little")
+    hdr[32:36] = (12).to_bytes(4, "little")
+    info = iqfile.parse_header(bytes(hdr))
+    assert info.file_format == 2 and info.header_bytes == 112 and info.bytes_per_sample == 4
+    assert (info.packet.frequencyHz, info.packet.sampleRateSps, info.packet.numSamples, info.packet.bitWidth) == \
+        (2_412_000_000, 56_000_000, 1234, 12)
 
 
 @needs_ref
@@ -133,8 +148,33 @@ def test_pulse_generator_switches():
     lfm = synth.pulse_phase(k, 1e6, fs, pw, lfm_extent_hz=2e6)
     inst = np.diff(lfm) * fs / (2 * np.pi)                                       # instantaneous frequency
     assert abs(inst[0] - 1e6) < 1e3 and abs(inst[-1] - 3e6) < 1e3 and np.all(np.diff(inst) > 0)
+    # reference behaviour (default): generate_pulsed_iq.m:49-59 adds +-90 to a phase held in RADIANS (it goes straight
+    # into exp(1j*my_phi), :62), so the chip states are 180 rad = 233.5 degrees (mod 360) apart
     bk = synth.pulse_phase(k, 0.0, fs, 13 * 431, barker13=True)
-    chips = np.rad2deg(bk[::431][:13])
-    assert np.allclose(np.sign(chips), synth.BARKER_13) and np.allclose(np.abs(chips), 90.0, atol=1e-6)
+    chips = bk[::431][:13]
+    assert np.allclose(np.sign(chips), synth.BARKER_13) and np.allclose(np.abs(chips), 90.0, atol=1e-9)
+    step = np.rad2deg(np.angle(np.exp(1j * (chips[5] - chips[4]))))              # a +1 -> -1 chip boundary
+    assert abs(abs(step) - (360.0 - np.rad2deg(180.0) % 360.0)) < 1e-6 or abs(abs(step) - np.rad2deg(180.0) % 360.0) < 1e-6
+    # the textbook code, behind the switch: +-90 degrees, chips 180 degrees apart
+    fixed = np.rad2deg(synth.pulse_phase(k, 0.0, fs, 13 * 431, barker13=True, matlab_quirks=False)[::431][:13])
+    assert np.allclose(np.sign(fixed), synth.BARKER_13) and np.allclose(np.abs(fixed), 90.0, atol=1e-6)
     a = synth.pulsed_iq_numpy(60000, 12, np.int16, lfm_extent_hz=5e6, barker13=True)
     assert a.shape == (60000, 2) and np.abs(a).max() <= 2048
+
+
+def test_counter_based_stream_is_identical_on_numpy_and_torch():
+    """sample index -> value, so the host twin and the device generator agree bit for bit and any
+    shard can be generated on its own.  (torch on the CPU device here; tests/test_gpu_parity.py repeats it on the GPU.)"""
+    import torch
+    from sdr_channelizer_amd import synth
+    for bw, dt, tdt in ((12, np.int16, torch.int16), (8, np.int8, torch.int8), (16, np.int16, torch.int16)):
+        for start, n in ((0, 120_000), ((1 << 33) + 12345, 60_000), (55_990, 200)):
+            a = synth.pulsed_iq_counter_numpy(n, bw, dt, start=start)
+            b = synth.pulsed_iq_torch(n, bw, tdt, device="cpu", start=start, chunk=50_001).numpy()
+            assert np.array_equal(a, b), (bw, start)
+    whole = synth.pulsed_iq_counter_numpy(3000, 12, np.int16)
+    assert np.array_equal(synth.pulsed_iq_counter_numpy(1000, 12, np.int16, start=700), whole[700:1700])
+    x = synth.pulsed_iq_counter_numpy(1 << 18, 12, np.int16).astype(np.float64)
+    on = (np.arange(1 << 18) % 56000) < 5600
+    assert abs(np.hypot(x[on, 0], x[on, 1]).mean() - 1024) < 5           # 0.5 full scale
+    assert abs(x[~on].std() - 32.0) < 0.5 and abs(x[~on].mean()) < 0.5    # sigma = 2^-6 full scale, zero mean

@@ -1,7 +1,8 @@
 """N>1 host logic on CPU (gloo, world_size 2): segment cutting and the halo exchange of
-sdr_channelizer_amd/sharded.py.  The per-rank arithmetic is stood in for by the ORACLE (as the
-checker -- there is no GPU here and the product has no CPU path): sharded == single stream,
-bit for bit, because the halo is raw input samples."""
+sdr_channelizer_amd/sharded.py -- the same callback (make_exchange, p2p and all_gather forms) the C library calls
+from pfb_process_shard_async, here driven with host pointers.  The per-rank arithmetic is stood in for by the ORACLE
+(as the checker -- there is no GPU here and the product has no CPU path): sharded == single stream, bit for bit,
+because the halo is raw input samples, and exactly M*P - D of them ((P-1)*M at D = M)."""
 import os
 import socket
 
@@ -19,32 +20,55 @@ from sdr_channelizer_amd.sharded import (ShardedChannelizer, exchange_halo, exch
 M, P, D, BW = 16, 4, 8, 12
 
 
+HALO = M * P - D  # M*P - 1 - input_offset with the default offset D - 1: what pfb_halo_samples() returns
+
+
 class OracleBackedChannelizer:
-    """Test double with the Channelizer surface ShardedChannelizer uses; float64 oracle inside."""
+    """Test double with the Channelizer surface ShardedChannelizer uses (attach_shard / process_shard / reset /
+    set_frame_index / sync); float64 oracle inside, host memory, and the same exchange callback contract as the library:
+    exchange(d_send, d_recv, nbytes, send_to, recv_from, stream) with raw pointers."""
+
+    decimation = D
+    halo_samples = HALO
 
     def __init__(self, taps):
         self.o = COracle()
         self.taps = np.asarray(taps, np.float64)
-        self.history_samples = M * P + D
+        self.rank, self.world, self.exchange, self.ring = 0, 1, None, False
+        self.last_halo = None
         self.reset()
 
     def reset(self):
-        self.hist = np.zeros((self.history_samples, 2), np.int16)
+        self.state = np.zeros((HALO, 2), np.int16)  # the stream's own past (zeros after reset)
         self.frame_index = 0
-
-    def prime(self, iq):
-        iq = np.asarray(iq).reshape(-1, 2)
-        self.hist = np.concatenate([self.hist, iq])[-self.history_samples:]
 
     def set_frame_index(self, f):
         self.frame_index = f
 
-    def __call__(self, seg, out=None):
-        seg = np.asarray(seg).reshape(-1, 2)
-        x = self.o.unpack(np.concatenate([self.hist, seg]), BW)
+    def sync(self):
+        pass
+
+    def attach_shard(self, rank, world, exchange=None, ring=False):
+        self.rank, self.world, self.exchange, self.ring = rank, world, exchange, ring
+
+    def process_shard(self, seg, out=None):
+        seg = np.ascontiguousarray(np.asarray(seg).reshape(-1, 2))
+        assert seg.shape[0] % D == 0 and seg.shape[0] > HALO
+        receiving = self.world > 1 and (self.ring or self.rank > 0)
+        sending = self.world > 1 and (self.ring or self.rank + 1 < self.world)
+        tail = np.ascontiguousarray(seg[-HALO:])
+        halo = np.zeros((HALO, 2), np.int16)
+        if sending or receiving:
+            rc = self.exchange(tail.ctypes.data if sending else 0, halo.ctypes.data if receiving else 0, HALO * 4,
+                               (self.rank + 1) % self.world if sending else -1,
+                               (self.rank - 1) % self.world if receiving else -1, 0)
+            assert rc == 0
+        before = halo if receiving else self.state
+        self.last_halo = before.copy()
+        x = self.o.unpack(np.concatenate([before, seg]), BW)
         y = self.o.channelize(x, self.taps, OracleConfig(M, P, D))
-        self.prime(seg)
-        return y[self.history_samples // D:]
+        self.state = tail.copy()
+        return y[HALO // D:]  # HALO is a whole number of frames: the rest are the segment's own
 
 
 def _free_port():
@@ -53,7 +77,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, total, taps, ret):
+def _worker(rank, world, port, total, taps, mode, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -61,15 +85,20 @@ def _worker(rank, world, port, total, taps, ret):
         bounds = segment_bounds(total, world, D)
         s, e = bounds[rank]
         seg = torch.from_numpy(synth.pulsed_iq_numpy(e - s, BW, np.int16, seed=4, start=s))
-        sc = ShardedChannelizer(OracleBackedChannelizer(taps), rank, world)
+        ch = OracleBackedChannelizer(taps)
+        sc = ShardedChannelizer(ch, rank, world, mode=mode)  # the library's callback contract over gloo, host pointers
         y = sc.process_segment(seg, first_frame=s // D)
+        got_halo = ch.last_halo.copy()
         # ring variant used by bench.py: everyone receives, rank 0 from the last rank
-        halo = torch.zeros((M * P + D, 2), dtype=torch.int16)
-        exchange_halo(seg[-(M * P + D):].contiguous(), halo, rank, world, ring=True)
-        halo2 = torch.zeros((M * P + D, 2), dtype=torch.int16)   # the same ring as one all_gather
-        exchange_halo_allgather(seg[-(M * P + D):].contiguous(), halo2, rank, world)
-        assert torch.equal(halo2, halo)
-        ret[rank] = (np.asarray(y), halo.numpy().copy(), seg.numpy()[-(M * P + D):].copy())
+        ring = OracleBackedChannelizer(taps)
+        ShardedChannelizer(ring, rank, world, mode=mode, ring=True).process_segment(seg, first_frame=s // D)
+        # the tensor-level helpers agree with each other
+        halo = torch.zeros((HALO, 2), dtype=torch.int16)
+        exchange_halo(seg[-HALO:].contiguous(), halo, rank, world, ring=True)
+        halo2 = torch.zeros((HALO, 2), dtype=torch.int16)
+        exchange_halo_allgather(seg[-HALO:].contiguous(), halo2, rank, world)
+        assert torch.equal(halo2, halo) and np.array_equal(ring.last_halo, halo.numpy())
+        ret[rank] = (np.asarray(y), halo.numpy().copy(), seg.numpy()[-HALO:].copy(), got_halo)
     finally:
         dist.destroy_process_group()
 
@@ -82,12 +111,13 @@ def test_segment_bounds():
 
 
 @pytest.mark.timeout(120)
-def test_two_rank_time_sharding_matches_single_stream():
+@pytest.mark.parametrize("mode", ["p2p", "allgather"])
+def test_two_rank_time_sharding_matches_single_stream(mode):
     world, total = 2, D * 400
     taps = np.random.default_rng(0).standard_normal(M * P)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), total, taps, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), total, taps, mode, ret), nprocs=world, join=True)
     iq = np.concatenate([synth.pulsed_iq_numpy(e - s, BW, np.int16, seed=4, start=s)
                          for s, e in segment_bounds(total, world, D)])
     o = COracle()
@@ -97,6 +127,8 @@ def test_two_rank_time_sharding_matches_single_stream():
     assert np.array_equal(sharded, single)  # raw-sample halo => identical bits
     for r in range(world):  # ring: each rank holds its predecessor's tail
         assert np.array_equal(ret[r][1], ret[(r - 1) % world][2])
+    # open chain: rank 0 continued from its own (zero) state, rank 1 from exactly (P-1)*M... = M*P - D samples of rank 0
+    assert not ret[0][3].any() and np.array_equal(ret[1][3], ret[0][2]) and ret[1][3].shape[0] == M * P - D
 
 
 def _folder_worker(rank, world, port, paths, ret):
