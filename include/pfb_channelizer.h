@@ -254,7 +254,9 @@ typedef enum pfb_option {
                                 /* 7 = a FIR wave + an FFT wave per long sliding run;            */
                                 /* channel-major handles: 0 / 2 as above, 8 = short runs whose   */
                                 /* output is transposed in LDS, 9 = frame-major slabs + a        */
-                                /* transpose kernel (the default of the M = 1024 / 560 plans)    */
+                                /* transpose kernel, 10 = the team kernel with its output tiles  */
+                                /* transposed through an L2-resident scratch (the default of the */
+                                /* M = 1024 / 560 plans; PFB_OPT_TILE_WAVES 16 = 16-frame tiles) */
   PFB_OPT_GRID = 7,             /* schedules 1/5: workgroups to launch (0 = all that are resident) */
   PFB_OPT_TILE_WAVES = 8,       /* schedules 2/3: waves, 4/5/7: wave pairs per workgroup         */
   PFB_OPT_EXPERIMENT = 9,       /* bit mask of timing experiments; 0 in production               */

@@ -94,7 +94,7 @@ struct pfb_handle {
   int opt_grid = 0;
   int opt_tile_waves = 8;
   int64_t opt_slab_frames = 0;  // channel-major by slabs: frames per slab (0 = ~32 MiB of output)
-  void* d_slab = nullptr;       // frame-major scratch of the slab path
+  void* d_slab = nullptr;       // frame-major scratch of the slab path (and the tiles of schedule 10)
   size_t slab_bytes = 0;
   void* d_matrix = nullptr;     // pfb_pdw_from_iq_file: the record's channel matrix (grow-only)
   size_t matrix_bytes = 0;
@@ -221,7 +221,12 @@ int launch_frames(pfb_handle* h, const void* d_iq, uint64_t n, const void* hist,
   // any shape, PFB_OPT_SLAB_FRAMES sets their length.
   const bool cm = h->layout == PFB_LAYOUT_CHANNEL_MAJOR;
   const bool forced_fused = h->opt_schedule == 0 || h->opt_schedule == 2 || h->opt_schedule == 8;
-  const bool by_slabs = cm && want_fast && (!h->fast->channel_major_ok || h->opt_schedule == 9);
+  // Team plans also have a fused route (schedule 10): the frame-major kernel itself, resident workgroups, each writing
+  // tiles of cm_tile_frames frames into its own scratch slot (rewritten every other tile) and its FFT waves transposing
+  // them into place -- no slab, no second kernel.  Bit-identical, but slower than the slabs.
+  const bool by_tiles = cm && want_fast && h->fast->cm_tile_frames > 0 && !(h->flags & PFB_FLAG_MAGNITUDE) &&
+                        h->opt_schedule == 10;  // measured SLOWER than the slabs (7.4 vs 6.4 ms per 2^30 at M = 1024): opt-in only
+  const bool by_slabs = cm && want_fast && !by_tiles && (!h->fast->channel_major_ok || h->opt_schedule == 9);
   if (want_fast) {
     const int c = h->fast->chunk_frames;
     int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
@@ -232,6 +237,7 @@ int launch_frames(pfb_handle* h, const void* d_iq, uint64_t n, const void* hist,
     }
     if (cm && !by_slabs)  // fused channel-major: 0 = sliding runs, 2 = tiles, 8 = short runs transposed in LDS, else the kernel's pick
       p.schedule = forced_fused ? h->opt_schedule : -1;
+    if (by_tiles) p.schedule = 10;
     if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
     if (p.schedule == 6 || p.schedule == 7) fpb = ((fpb + 2 * c - 1) / (2 * c)) * (2 * c);  // these kernels walk chunks in pairs
     if (p.schedule == 4 || p.schedule == 5) {
@@ -240,6 +246,20 @@ int launch_frames(pfb_handle* h, const void* d_iq, uint64_t n, const void* hist,
     }
     // short sliding runs in dispatch order already sweep the stream as one window: leave them round-robin over the XCDs
     if (p.schedule == 0 && fpb <= 64 && h->opt_xcd_remap < 0) p.xcd_remap = 0;
+    if (by_tiles) {
+      fpb = std::max(32, (fpb + 31) / 32 * 32);  // whole tiles (of 32 or 16 frames), chunks in pairs
+      const int slots = h->num_cus;              // one workgroup per CU is resident (LDS); the launcher clamps its grid
+      const size_t need = (size_t)slots * 2 * h->fast->cm_tile_frames * h->M * sizeof(float2);  // two tiles per slot
+      if (need > h->slab_bytes) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_slab);
+        h->d_slab = nullptr; h->slab_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_slab, need));
+        h->slab_bytes = need;
+      }
+      p.scratch = h->d_slab;
+      p.scratch_slots = slots;
+    }
     p.frames_per_block = fpb;
     const int cpt = h->fast->cols_per_thread;
     const int bmod = ((p.base % cpt) + cpt) % cpt;
@@ -250,6 +270,8 @@ int launch_frames(pfb_handle* h, const void* d_iq, uint64_t n, const void* hist,
       sf = std::max<long long>(sf, (h->hist_samples + h->D - 1) / h->D + 1);  // a later slab's window reaches back into the input, never into the history
       sf = std::min<long long>(sf, 65535ll * 64);  // the transpose kernel's grid: one row of 64 x 64 tiles per 64 frames
       sf = std::min<long long>(sf, ((long long)frames + 63) / 64 * 64);
+      // (tried: two slabs and a side stream, slab k transposed while slab k + 1 is filled -- 6.9 ms instead of 6.4 per 2^30
+      // samples at M = 1024: the two kernels slow each other down by more than the overlap buys.  One slab, one stream.)
       const size_t need = (size_t)sf * h->M * h->out_elem;
       if (need > h->slab_bytes) {
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1096,7 +1118,7 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_nontemporal = value ? 1 : 0;
       return PFB_OK;
     case PFB_OPT_SCHEDULE:
-      if (value < -1 || value > 9) return PFB_ERR_BAD_ARG;
+      if (value < -1 || value > 10) return PFB_ERR_BAD_ARG;
       h->opt_schedule = (int)value;
       return PFB_OK;
     case PFB_OPT_TILE_WAVES:
@@ -1113,6 +1135,8 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       return PFB_OK;
     case PFB_OPT_EXPERIMENT:
       h->opt_experiment = (int)value;
+      pfb::g_transpose_probe = (int)((value >> 16) & 3);
+      if (((value >> 20) & 0xfff) != 0) pfb::g_transpose_tile_frames = (int)((value >> 20) & 0xfff);  // tuning: slab transposer tile
       return PFB_OK;
     case PFB_OPT_SLAB_FRAMES:
       if (value < 0 || value > (1ll << 32)) return PFB_ERR_BAD_ARG;

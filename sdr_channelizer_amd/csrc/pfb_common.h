@@ -57,6 +57,8 @@ struct KernelParams {
                            //               2 = one chunk per wave, tile_waves chunks per workgroup
   int tile_waves;          // schedule 2: waves (= adjacent chunks) per workgroup: 1, 2, 4, 8 or 16
   int grid_override;       // schedule 1: workgroups to launch (0 = what is resident at once)
+  void* scratch;           // schedule 10: scratch_slots x 2 tiles of cm_tile_frames x M complex64, a slot per resident workgroup
+  int scratch_slots;
 };
 
 // sample traits -----------------------------------------------------------------
@@ -106,6 +108,7 @@ struct FastKernelInfo {
   int default_schedule;    // measured best schedule for this instantiation (PFB_OPT_SCHEDULE = -1)
   bool channel_major_ok;   // has a channel-major instantiation
   int magnitude_schedule;  // measured best schedule with PFB_FLAG_MAGNITUDE, -1 = default_schedule
+  int cm_tile_frames;      // > 0: the team kernel has a fused channel-major route (schedule 10) with tiles of this many frames
 };
 const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant = 0, bool channel_major = false);
 
@@ -115,5 +118,7 @@ hipError_t launch_update_history(const void* old_hist, const void* in, long long
 hipError_t launch_transpose_slab(const void* slab, long long frames, int M, void* out, long long out_ld,
                                  long long out_frame0, int elem_bytes, hipStream_t s);
 hipError_t launch_stream_copy(const void* in, void* out, long long n_vec16, hipStream_t s);
+extern int g_transpose_probe;
+extern int g_transpose_tile_frames;  // frames per tile of the slab transposer: 64, 128 or 256
 
 }  // namespace pfb

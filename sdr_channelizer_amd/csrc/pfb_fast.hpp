@@ -403,9 +403,12 @@ struct FastKernel {
     }
   }
 
+  // out_base / frames_lim: the last pass's destination when it is not p.out (the team kernel's scratch tile)
   template <int I>
   PFB_DEV void pass(const KernelParams& p, float2* src, float2* dst, int tid, long long f0,
-                    const v2f (&tw)[2][16]) {
+                    const v2f (&tw)[2][16], float2* out_base = nullptr, long long frames_lim = -1) {
+    float2* const p_out = out_base ? out_base : p.out;
+    const long long p_frames = frames_lim >= 0 ? frames_lim : p.frames;
     constexpr int R = K::R(I), S = K::S(I), KK = K::K(I), RS = K::RS(I);
     constexpr int IPF = M / R, ITEMS = C * IPF, ITERS = (ITEMS + NT - 1) / NT;
     constexpr bool LAST = (I == K::NP - 1);
@@ -477,16 +480,16 @@ struct FastKernel {
 #pragma unroll
             for (int j = 0; j < (NV + 63) / 64; ++j) {
               const int idx = tid + 64 * j, fr = idx / (M / 4), q = idx % (M / 4);
-              if ((NV % 64 == 0 || idx < NV) && f0 + fr < p.frames) {
+              if ((NV % 64 == 0 || idx < NV) && f0 + fr < p_frames) {
                 const float4 v = *reinterpret_cast<const float4*>(stage + fr * SR + q * 4);
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (f0 + fr) * M + q * 4) = v;
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p_out) + (f0 + fr) * M + q * 4) = v;
               }
             }
             return;
           }
         }
         const long long f = f0 + fc;
-        if (active && f < p.frames) {
+        if (active && f < p_frames) {
           const bool flip_odd = (OS == 2) && (p.flags & PFB_FLAG_DEROTATE) && ((p.frame0 + f) & 1);
           const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
           // fftshift(out,2): column (k + M/2) mod M.  For a power-of-two M that swaps the two halves of
@@ -516,7 +519,7 @@ struct FastKernel {
             const long long esz = mag ? 4 : 8;
             const long long cs = CM ? p.out_ld : 1;  // elements between adjacent channels
             int col = col_of(kk);
-            char* ptr = reinterpret_cast<char*>(p.out) + ((long long)col * cs + (CM ? p.out_frame0 + f : f * M)) * esz;
+            char* ptr = reinterpret_cast<char*>(p_out) + ((long long)col * cs + (CM ? p.out_frame0 + f : f * M)) * esz;
             const long long step = (long long)KK * cs * esz, wrap = (long long)M * cs * esz;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -533,11 +536,11 @@ struct FastKernel {
               if (col >= M) { col -= M; ptr -= wrap; }
             }
           } else if (p.flags & PFB_FLAG_MAGNITUDE) {  // fused abs(): 4 bytes per channel instead of 8
-            float* rowm = reinterpret_cast<float*>(p.out) + f0 * M + fc * M;
+            float* rowm = reinterpret_cast<float*>(p_out) + f0 * M + fc * M;
 #pragma unroll
             for (int k = 0; k < R; ++k) *slot(rowm, k) = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
           } else {
-            float2* row = p.out + f0 * M + fc * M;
+            float2* row = p_out + f0 * M + fc * M;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
               const int ch = kk + k * KK;
@@ -857,10 +860,26 @@ struct FastKernel {
   // FIR team: chunk ci into buffer ci % 3, then the LAST pass (and the stores) of chunk ci - 2, whose first two
   // passes the FFT team finished in the step before.  The stores are most of the FFT's memory work and the FIR
   // team has issue slots to spare, while four FFT waves doing everything were the bottleneck (2.4 of 2.9 ms).
-  template <bool INTERIOR>
-  PFB_DEV void fir_team(const KernelParams& p, const Consts& k, float2* bufs, long long f_begin, int nch) {
+  // TF > 0 (channel-major handles): the last pass writes its frame-major rows into one of this workgroup's two scratch
+  // tiles of TF frames (global memory, rewritten every other tile, so it lives in L2 / the memory-side cache) instead of
+  // `out`; the FFT team moves finished tiles into place transposed, a slice per chunk step (flush_unit below).  The FIR
+  // team's only extra duty: at a tile's last chunk its stores must have LEFT before the step's barrier.
+  template <bool INTERIOR, int TF = 0>
+  PFB_DEV void fir_team(const KernelParams& p, const Consts& k, float2* bufs, long long f_begin, int nch,
+                        float2* sc = nullptr, int tile_base = 0) {
     const int tid = threadIdx.x;
     const int c0 = tid * CPT;
+    static_assert(TF == 0 || (OS == 1 && TF % C == 0), "critically sampled team plans, whole chunks per tile");
+    constexpr int CPTL = TF > 0 ? TF / C : 1;  // chunks per tile
+    auto last_pass = [&](float2* buf, int c) {   // chunk c of this run
+      if constexpr (TF > 0) {
+        float2* tile = sc + (size_t)((tile_base + c / CPTL) & 1) * TF * M;
+        pass<K::NP - 1>(p, buf, nullptr, tid, (long long)(c % CPTL) * C, k.tw, tile, TF);
+        if (c % CPTL == CPTL - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile is complete: visible behind the next barrier
+      } else {
+        pass<K::NP - 1>(p, buf, nullptr, tid, f_begin + (long long)c * C, k.tw);
+      }
+    };
     const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
     v2f x[NW][CPT];
     raw_t raw[2][C][CPT];  // two chunks of rows in flight: one chunk is only ~1.5 us of work, less than a loaded HBM round trip
@@ -890,57 +909,185 @@ struct FastKernel {
 #pragma unroll
           for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f0 + 2 * C + t, rel + t, c0, raw[u][t]);
         }
+        // (TF > 0: the stores first, so that at a tile's end they have the FIR's time to leave before the wait for them)
+        if constexpr (TF > 0) { if (ci >= 2) pass<K::NP - 1>(p, bufs + b_last * K::BUF, nullptr, tid, (long long)((ci - 2) % CPTL) * C, k.tw,
+                                                              sc + (size_t)((tile_base + (ci - 2) / CPTL) & 1) * TF * M, TF); }
         fir_to_lds(k, x, bufs + b_fir * K::BUF, tid);
 #pragma unroll
         for (int i = 0; i < W - 1; ++i)
 #pragma unroll
           for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
-        if (ci >= 2) pass<K::NP - 1>(p, bufs + b_last * K::BUF, nullptr, tid, f0 - 2 * C, k.tw);
-        __syncthreads();  // chunk ci handed to the FFT team, buffer of chunk ci - 2 free again
+        if constexpr (TF > 0) {
+          if (ci >= 2 && (ci - 2) % CPTL == CPTL - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile is complete: visible behind the barrier
+        } else {
+          if (ci >= 2) last_pass(bufs + b_last * K::BUF, ci - 2);
+        }
+        __syncthreads();  // (barrier ci) chunk ci handed to the FFT team, buffer of chunk ci - 2 free again
         b_fir = (b_fir == 2) ? 0 : b_fir + 1;
         b_last = (b_last == 2) ? 0 : b_last + 1;
       }
     }
     // drain: the FFT team finishes chunk nch - 1 while chunk nch - 2 gets its last pass, then chunk nch - 1
-    if (nch >= 2) pass<K::NP - 1>(p, bufs + b_last * K::BUF, nullptr, tid, f_begin + (long long)(nch - 2) * C, k.tw);
-    __syncthreads();
+    if (nch >= 2) last_pass(bufs + b_last * K::BUF, nch - 2);
+    __syncthreads();  // (barrier nch)
     b_last = (b_last == 2) ? 0 : b_last + 1;
-    pass<K::NP - 1>(p, bufs + b_last * K::BUF, nullptr, tid, f_begin + (long long)(nch - 1) * C, k.tw);
+    last_pass(bufs + b_last * K::BUF, nch - 1);
+    if constexpr (TF > 0) __syncthreads();  // (barrier nch + 1) the run's last tile handed to the FFT team
   }
 
-  PFB_DEV void run_teams(const KernelParams& p, float2* bufs) {
-    static_assert(K::NP == 3 && !K::PINGPONG && NT % 64 == 0, "three in-place passes");
-    long long run = blockIdx.x;
-    if (p.xcd_remap) {  // consecutive runs on one XCD: a run's halo rows are its predecessor's last rows, still in that L2
-      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
-      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
-    }
-    const long long f_begin = run * p.frames_per_block;
-    if (f_begin >= p.frames) return;
-    const int nch = p.frames_per_block / C;  // even (host rounds); the last workgroup filters zero padding past the end
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave < NT / 64) {
-      Consts k;
-      setup(p, threadIdx.x, k);
-      const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_begin + p.frames_per_block <= p.frames);
-      if (interior) fir_team<true>(p, k, bufs, f_begin, nch);
-      else fir_team<false>(p, k, bufs, f_begin, nch);
-    } else {
-      const int fr = wave - NT / 64;  // my frame inside every chunk
-      Consts k;
-      setup(p, lane, k);  // only the twiddles are used: rows `lane % S` of the passes' tables
-      int b = 0;          // buffer of chunk s - 1
-#pragma unroll 1
-      for (int s = 0; s <= nch; ++s) {
-        if (s >= 1) {
-          float2* fbuf = bufs + b * K::BUF + fr * K::FS;
-          pass_frame<0>(p, fbuf, lane, k.tw);
-          team_sync<true>();
-          pass_frame<1>(p, fbuf, lane, k.tw);
-          b = (b == 2) ? 0 : b + 1;
-        }
-        __syncthreads();
+  // One slice of a finished tile, by ONE FFT wave with its own small LDS tile (no workgroup barrier involved): unit u =
+  // 32 channels x TF frames of the frame-major scratch tile -> TF consecutive frames of 32 channel rows of `out`
+  // (256-byte runs at TF = 32, two channels per store instruction).  The scratch reads bypass L1 (nontemporal:
+  // L2-served), so what the last pass wrote a moment ago is what comes back whatever this CU's L1 holds from before.
+  template <int TF>
+  struct TileFlush {
+    static constexpr int TROW = TF + 1, TILE = 32 * TROW;  // per FFT wave; padded rows: conflict-free transposed writes
+    static constexpr int UNITS = (M + 31) / 32;            // per tile
+    static constexpr int STEPS = TF / C;                   // chunk steps until the scratch tile is written again
+    static constexpr int UPS = (UNITS + C * STEPS - 1) / (C * STEPS);  // units per FFT wave and step
+    static_assert(TF % 2 == 0 && (64 * TF) % 64 == 0, "two frames per load instruction");
+  };
+
+  // the two halves of a unit's flush: the loads are issued at the top of a chunk step and land under the step's FFT
+  // passes; transposition and stores follow the passes (a dependent load -> LDS -> store chain inside one step made the
+  // FFT waves the kernel's critical path: 5.9 ms instead of 2.7 per 2^30 samples at M = 1024)
+  template <int TF>
+  PFB_DEV void flush_load(const float2* tile, int u, int lane, v2f (&v)[TF / 2]) {
+    const int ch0 = u * 32;
+    if (ch0 >= M) return;  // wave-uniform
+    const int lc = lane & 31, lf = lane >> 5;
+    const v2f* src = reinterpret_cast<const v2f*>(tile) + (ch0 + lc < M ? ch0 + lc : 0);
+#pragma unroll
+    for (int i = 0; i < TF / 2; ++i) v[i] = __builtin_nontemporal_load(src + (size_t)(2 * i + lf) * M);
+  }
+
+  template <int TF>
+  PFB_DEV void flush_store(const KernelParams& p, float2* lds_tile, int u, long long f_tile0, int lane, const v2f (&v)[TF / 2]) {
+    constexpr int TROW = TileFlush<TF>::TROW;
+    static_assert(M % 2 == 0 && TF == 32, "a store instruction is two channels x 32 frames");
+    const int ch0 = u * 32;
+    if (ch0 >= M) return;  // wave-uniform
+    v2f* T = reinterpret_cast<v2f*>(lds_tile);
+    const int lc = lane & 31, lf = lane >> 5;
+    v2f* wr = T + lc * TROW + lf;  // + 2 i: immediate offsets
+#pragma unroll
+    for (int i = 0; i < TF / 2; ++i) wr[2 * i] = v[i];
+    team_sync<true>();
+    // element i of this lane: channel ch0 + 2 i + lf, frame lc.  One LDS address and one global pointer, both advanced
+    // by constants (the opaque asm keeps the compiler from materialising sixteen 64-bit addresses: they spilled, and every
+    // reload sat behind an s_waitcnt vmcnt(0), i.e. behind the previous STORE's acknowledgement: 12 ms instead of 4)
+    const v2f* rd = T + lf * TROW + lc;  // + i * 2 * TROW
+    const long long fg = f_tile0 + lc;
+    typedef __attribute__((address_space(1))) v2f gv2f;  // stays a GLOBAL pointer behind the asm (a generic one becomes flat_store)
+    gv2f* ptr = (gv2f*)(p.out + (long long)(ch0 + lf) * p.out_ld + p.out_frame0 + fg);
+    const long long step = 2 * p.out_ld;
+    v2f val[TF / 2];
+#pragma unroll
+    for (int i = 0; i < TF / 2; ++i) val[i] = rd[i * 2 * TROW];
+    if (fg < p.frames) {
+#pragma unroll
+      for (int i = 0; i < TF / 2; ++i) {
+        if (M % 32 == 0 || ch0 + 2 * i < M) *ptr = val[i];  // wave-uniform: M is even, so a pair of channels is in or out together
+        asm volatile("" : "+v"(ptr) : : "memory");
+        ptr += step;
       }
+    }
+    team_sync<true>();  // the next unit overwrites the LDS tile
+  }
+
+  template <int TF = 0>
+  PFB_DEV void run_teams(const KernelParams& p, float2* bufs, float2* tiles = nullptr) {
+    static_assert(K::NP == 3 && !K::PINGPONG && NT % 64 == 0, "three in-place passes");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nch = p.frames_per_block / C;  // even (host rounds); the last workgroup filters zero padding past the end
+    Consts k;
+    setup(p, wave < NT / 64 ? threadIdx.x : lane, k);  // FFT team: only the twiddles are used, rows `lane % S` of the passes' tables
+    // frame-major: one run per workgroup, in dispatch order.  TF > 0: resident workgroups walk runs b, b + G, ... and
+    // own scratch slot b (two tiles; the grid is what fits the chip at once, so the scratch is 2 x TF frames per CU)
+    using TFL = TileFlush<(TF > 0 ? TF : 2 * C)>;
+    constexpr int CPTL = TF > 0 ? TF / C : 1, TPR_DUMMY = 0;
+    (void)TPR_DUMMY;
+    const long long nruns = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
+    float2* sc = TF > 0 ? reinterpret_cast<float2*>(p.scratch) + (size_t)blockIdx.x * 2 * TF * M : nullptr;
+    const int tiles_per_run = TF > 0 ? nch / CPTL : 0;
+    int tile_base = 0;  // tiles this workgroup has produced before the current run (parity picks the scratch tile)
+    // FFT team: the tile being flushed
+    int pend = 0, pend_buf = 0;
+    long long pend_f0 = 0;
+    const int fr = wave - NT / 64;  // FFT team: my frame inside every chunk
+    v2f fv[TFL::UPS][(TF > 0 ? TF : 2 * C) / 2];  // the slice in flight
+    bool loaded = false;            // fv holds the slice the next flush_end stores
+    auto flush_fetch = [&]() {
+      if constexpr (TF > 0) {
+        const int j = TFL::STEPS - pend;
+#pragma unroll
+        for (int q = 0; q < TFL::UPS; ++q)
+          flush_load<TF>(sc + (size_t)pend_buf * TF * M, (j * TFL::UPS + q) * C + fr, lane, fv[q]);
+        loaded = true;
+      }
+    };
+    auto flush_begin = [&]() {      // FFT team, top of a chunk step: a tile's FIRST slice is loaded here ...
+      if constexpr (TF > 0) {
+        if (pend > 0 && !loaded) flush_fetch();
+      }
+    };
+    auto flush_end = [&]() {        // ... after the step's FFT passes the slice goes through LDS and out, and the NEXT slice's
+      if constexpr (TF > 0) {       // loads are issued behind the stores: a whole chunk step for both to complete
+        if (pend > 0) {
+          const int j = TFL::STEPS - pend;
+#pragma unroll
+          for (int q = 0; q < TFL::UPS; ++q)
+            flush_store<TF>(p, tiles + fr * TFL::TILE, (j * TFL::UPS + q) * C + fr, pend_f0, lane, fv[q]);
+          --pend;
+          loaded = false;
+          if (pend > 0) flush_fetch();
+        }
+      }
+    };
+    for (long long blk = blockIdx.x; blk < nruns; blk += (TF > 0 ? (long long)gridDim.x : nruns)) {
+      long long run = blk;
+      if (TF == 0 && p.xcd_remap) {  // consecutive runs on one XCD: a run's halo rows are its predecessor's last rows, still in that L2
+        const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
+        run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
+      }
+      const long long f_begin = run * p.frames_per_block;
+      if (f_begin >= p.frames) break;
+      if (wave < NT / 64) {
+        const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_begin + p.frames_per_block <= p.frames);
+        if (interior) fir_team<true, TF>(p, k, bufs, f_begin, nch, sc, tile_base);
+        else fir_team<false, TF>(p, k, bufs, f_begin, nch, sc, tile_base);
+      } else {
+        int b = 0;          // buffer of chunk s - 1
+#pragma unroll 1
+        for (int s = 0; s <= nch; ++s) {
+          flush_begin();
+          if (s >= 1) {
+            float2* fbuf = bufs + b * K::BUF + fr * K::FS;
+            pass_frame<0>(p, fbuf, lane, k.tw);
+            team_sync<true>();
+            pass_frame<1>(p, fbuf, lane, k.tw);
+            b = (b == 2) ? 0 : b + 1;
+          }
+          flush_end();
+          __syncthreads();  // (barrier s) behind it the FIR team's last pass of chunk s - 2 is done -- and, at a tile's end, visible
+          if constexpr (TF > 0) {
+            if (s >= 2 && (s - 2) % CPTL == CPTL - 1) {
+              const int tc = (s - 2) / CPTL;
+              pend = TFL::STEPS; pend_buf = (tile_base + tc) & 1; pend_f0 = f_begin + (long long)tc * TF; loaded = false;
+            }
+          }
+        }
+        if constexpr (TF > 0) {
+          __syncthreads();  // (barrier nch + 1) the run's last tile
+          while (pend > 0) { flush_begin(); flush_end(); }  // the tile before it was a step short of done (the run ended)
+          pend = TFL::STEPS; pend_buf = (tile_base + tiles_per_run - 1) & 1; pend_f0 = f_begin + (long long)(tiles_per_run - 1) * TF;
+          loaded = false;
+        }
+      }
+      tile_base += tiles_per_run;
+    }
+    if constexpr (TF > 0) {
+      if (wave >= NT / 64) while (pend > 0) { flush_begin(); flush_end(); }  // the last tile of the last run: nobody to keep step with
     }
   }
 
@@ -1866,6 +2013,40 @@ __global__ void __launch_bounds__(K::NT + 64 * K::C, K::MIN_WAVES) pfb_teams_ker
   FastKernel<K>::run_teams(p, bufs);
 }
 
+// channel-major for the team plans: the same kernel with its output tile transposed through an L2-resident scratch
+// (FastKernel::flush_tile); frames_per_block must be a multiple of TF
+template <class K, int TF>
+constexpr bool kTeamsCmOk = kTeamsOk<K> && K::D == K::M && TF % K::C == 0 &&
+                            sizeof(float2) * (3 * K::BUF + K::C * FastKernel<K>::template TileFlush<TF>::TILE) <= 160 * 1024;
+
+template <class K, int TF>
+__global__ void __launch_bounds__(K::NT + 64 * K::C, K::MIN_WAVES) pfb_teams_cm_kernel(const KernelParams p) {
+  using TFL = typename FastKernel<K>::template TileFlush<TF>;
+  __shared__ float2 bufs[3 * K::BUF + K::C * TFL::TILE];
+  FastKernel<K>::template run_teams<TF>(p, bufs, bufs + 3 * K::BUF);
+}
+
+template <class K, int TF>
+hipError_t launch_teams_cm(const KernelParams& p, hipStream_t s) {
+  static int resident = 0;  // workgroups resident at once on this device class
+  if (resident == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pfb_teams_cm_kernel<K, TF>, K::NT + 64 * K::C, 0);
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    resident = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
+  }
+  const long long nruns = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
+  long long grid = p.grid_override > 0 ? p.grid_override : resident;
+  if (grid > nruns) grid = nruns;
+  if (grid > p.scratch_slots) grid = p.scratch_slots;  // one scratch tile per workgroup
+  if (grid < 1 || !p.scratch || p.frames_per_block % TF != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((pfb_teams_cm_kernel<K, TF>), dim3((unsigned)grid), dim3(K::NT + 64 * K::C), 0, s, p);
+  return hipGetLastError();
+}
+
 template <class K, int NWV, int L>
 hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s);
 
@@ -1912,8 +2093,16 @@ hipError_t launch_strided(const KernelParams& p, hipStream_t s) {  // persistent
 }
 
 template <class K>
+constexpr int kTeamsCmFrames = kTeamsCmOk<K, 32> ? 32 : 0;
+
+template <class K>
 hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   if (p.frames <= 0) return hipSuccess;
+  if constexpr (kTeamsCmFrames<K> > 0) {
+    if (p.layout == PFB_LAYOUT_CHANNEL_MAJOR && p.schedule == 10 && !(p.flags & PFB_FLAG_MAGNITUDE)) {
+      return launch_teams_cm<K, kTeamsCmFrames<K>>(p, s);
+    }
+  }
   if (p.layout == PFB_LAYOUT_CHANNEL_MAJOR) {  // schedules 8, 2 and 0; the others are frame-major tuning
     if constexpr (kChannelMajorOk<K>) {
       if constexpr (K::NT == 64) {

@@ -165,13 +165,15 @@ def test_channel_major_device_path_is_bit_identical_to_frame_major():
     (128, 12, 64, "int16", 12, ((2, 0), (8, 8), (8, 16), (9, 64))),
     (256, 8, 256, "int8", 8, ((0, 0), (8, 8), (9, 64))),
     (32, 12, 32, "int16", 12, ((8, 32), (9, 64))),
-    (1024, 16, 1024, "int16", 12, ((-1, 0), (9, 64), (9, 192))),
-    (560, 12, 560, "int16", 12, ((-1, 0), (9, 128))),
+    (1024, 16, 1024, "int16", 12, ((-1, 0), (10, 32), (9, 64), (9, 192))),
+    (560, 12, 560, "int16", 12, ((-1, 0), (10, 32), (9, 128))),
     (20, 12, 20, "int16", 12, ((0, 0), (9, 64)))])
 def test_channel_major_routes_are_bit_identical(M, P, D, fmt, bw, routes):
     """Channel-major output by every route -- the kernel's own stores (schedules 0 and 2), short runs transposed in LDS
-    (schedule 8; frames_per_block = frames per wave), frame-major slabs + the transpose kernel (schedule 9) -- with and
-    without fused abs(), over a stream cut into calls: the transposed frame-major result, bit for bit."""
+    (schedule 8; frames_per_block = frames per wave), frame-major slabs + the transpose kernel (schedule 9), the team
+    kernel with its tiles transposed through an L2-resident scratch (schedule 10, tiles of 32 or 16 frames; the default
+    of the team plans for complex output) -- with and without fused abs(), over a stream cut into calls: the transposed
+    frame-major result, bit for bit."""
     import torch
     n = D * 1500 + 11
     iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device="cuda")
@@ -190,6 +192,10 @@ def test_channel_major_routes_are_bit_identical(M, P, D, fmt, bw, routes):
                     b.set_option(L.PFB_OPT_TILE_WAVES, {8: 4, 16: 4, 32: 2}[arg])
                 if sched == 9:
                     b.set_option(L.PFB_OPT_SLAB_FRAMES, arg)
+                if sched == 10:
+                    b.set_option(L.PFB_OPT_TILE_WAVES, 16 if arg == 16 else 8)
+                    if mag:
+                        continue  # fused abs() keeps the slab route
                 got = b(iq)
                 assert torch.equal(got, want), (M, mag, sched, arg)
                 b.reset()
