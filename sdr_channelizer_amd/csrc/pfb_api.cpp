@@ -245,7 +245,7 @@ int launch_frames(pfb_handle* h, const void* d_iq, uint64_t n, const void* hist,
       if (h->opt_xcd_remap < 0) p.xcd_remap = 0;  // 512-frame workgroups: one dense sweep beats L2 halo hits
     }
     // short sliding runs in dispatch order already sweep the stream as one window: leave them round-robin over the XCDs
-    if (p.schedule == 0 && fpb <= 64 && h->opt_xcd_remap < 0) p.xcd_remap = 0;
+    if ((p.schedule == 0 || p.schedule == 11) && fpb <= 64 && h->opt_xcd_remap < 0) p.xcd_remap = 0;
     if (by_tiles) {
       fpb = std::max(32, (fpb + 31) / 32 * 32);  // whole tiles (of 32 or 16 frames), chunks in pairs
       const int slots = h->num_cus;              // one workgroup per CU is resident (LDS); the launcher clamps its grid
@@ -1118,7 +1118,7 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_nontemporal = value ? 1 : 0;
       return PFB_OK;
     case PFB_OPT_SCHEDULE:
-      if (value < -1 || value > 10) return PFB_ERR_BAD_ARG;
+      if (value < -1 || value > 11) return PFB_ERR_BAD_ARG;
       h->opt_schedule = (int)value;
       return PFB_OK;
     case PFB_OPT_TILE_WAVES:

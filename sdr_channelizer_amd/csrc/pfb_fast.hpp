@@ -541,6 +541,9 @@ struct FastKernel {
             for (int k = 0; k < R; ++k) *slot(rowm, k) = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
           } else {
             float2* row = p_out + f0 * M + fc * M;
+            // (probed: R/2 16-byte stores per lane instead of R 8-byte ones -- same bytes, half the store instructions,
+            // written in a wrong layout just for the timing -- gain 0.4 % cfg2, 1.5 % cfg5, 2 % cfg4, 2.7 % cfg3 BEFORE the
+            // lane exchange a correct layout needs (4 DPP moves per pair): not store-issue-bound, left alone)
 #pragma unroll
             for (int k = 0; k < R; ++k) {
               const int ch = kk + k * KK;
@@ -801,6 +804,123 @@ struct FastKernel {
     const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_last <= p.frames);
     if (interior) run_impl<true>(p, k, lds, f_begin, f_end);
     else run_impl<false>(p, k, lds, f_begin, f_end);
+  }
+
+  // ---- schedule P: schedule A software-pipelined inside the wave ---------------------------------------------------
+  // PMC of the sliding kernels (profiles/r02_rocprofv3_pmc_summary_all_shapes.txt): a wave spends 26-29 % of its cycles in
+  // VALU instructions and ~40 % parked on s_waitcnt -- the chunk is a dependent chain FIR -> LDS -> pass 0 -> LDS -> pass 1 ->
+  // stores, and at 2 waves per SIMD (the window lives in ~200 VGPRs) nothing else is there to issue meanwhile.  Here the
+  // FIR of chunk i + 1 (pure VALU on the register window) sits in the SAME basic block as pass 0 of chunk i (LDS reads,
+  // butterflies, LDS writes on the other of two chunk buffers), so the compiler's scheduler can fill the LDS round trips
+  // with the next chunk's FMAs; the branch outputs wait in registers and go to LDS after pass 1.  Rows are fetched two
+  // chunks ahead instead of one.  Same arithmetic per output as schedule A: bit-identical.
+  PFB_DEV void fir_compute(const Consts& k, const v2f (&x)[NW][CPT], v2f (&acc)[OS][CPT][C]) {
+#pragma unroll
+    for (int ph = 0; ph < OS; ++ph)
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) {
+#pragma unroll
+        for (int t = 0; t < C; ++t) acc[ph][cc][t] = (v2f){0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          const int j = ph + OS * q;
+#pragma unroll
+          for (int t = 0; t < C; ++t) {
+            if (j & 1) fma_tap_hi(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+            else fma_tap_lo(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+          }
+        }
+      }
+  }
+
+  PFB_DEV void fir_write(const Consts& k, const v2f (&acc)[OS][CPT][C], float2* buf, int tid) {
+    if (!(K::LANES < NT) || tid < K::LANES) {
+#pragma unroll
+      for (int ph = 0; ph < OS; ++ph)
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc)
+#pragma unroll
+          for (int t = 0; t < C; ++t) reinterpret_cast<v2f*>(buf)[t * K::FS + k.upos[ph][cc]] = acc[ph][cc][t] * k.conj_mul;
+    }
+  }
+
+  template <bool INTERIOR>
+  PFB_DEV void run_overlap_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end) {
+    static_assert(NT == 64 && K::NP == 2 && !K::PINGPONG, "single-wave two-pass plans");
+    const int tid = threadIdx.x;
+    const int c0 = tid * CPT;
+    const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
+    const long long nchunks = (f_end - f_begin + C - 1) / C;
+    v2f x[NW][CPT];
+    raw_t raw[C][CPT];
+    v2f acc[OS][CPT][C];
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) {
+      raw_t t[CPT];
+      load_row<INTERIOR>(p, run_ptr, f_begin - (W - 1) + i, i, c0, t);
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(t[cc]);
+    }
+    auto load_chunk_rows = [&](long long ci) {  // chunk ci of this run (clamped: the last chunk is fetched again rather than branching)
+      const long long cl = ci < nchunks ? ci : nchunks - 1;
+#pragma unroll
+      for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + cl * C + t, W - 1 + cl * C + t, c0, raw[t]);
+    };
+    auto take_rows = [&]() {
+#pragma unroll
+      for (int t = 0; t < C; ++t)
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);
+    };
+    auto slide = [&]() {
+#pragma unroll
+      for (int i = 0; i < W - 1; ++i)
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
+    };
+    // chunk 0 by itself
+    load_chunk_rows(0);
+    take_rows();
+    load_chunk_rows(1);
+    fir_compute(k, x, acc);
+    slide();
+    fir_write(k, acc, lds, tid);
+    team_sync<true>();
+    float2* cur = lds;
+    float2* nxt = lds + K::BUF;
+    for (long long ci = 0; ci + 1 < nchunks; ++ci) {
+      take_rows();                 // rows of chunk ci + 1 (waits for them)
+      load_chunk_rows(ci + 2);     // two chunks ahead
+      // one basic block: the next chunk's FIR next to this chunk's first pass
+      fir_compute(k, x, acc);
+      pass<0>(p, cur, cur, tid, f_begin + ci * C, k.tw);
+      slide();
+      team_sync<true>();
+      pass<1>(p, cur, nullptr, tid, f_begin + ci * C, k.tw);
+      fir_write(k, acc, nxt, tid);
+      team_sync<true>();
+      float2* t = cur; cur = nxt; nxt = t;
+    }
+    pass<0>(p, cur, cur, tid, f_begin + (nchunks - 1) * C, k.tw);
+    team_sync<true>();
+    pass<1>(p, cur, nullptr, tid, f_begin + (nchunks - 1) * C, k.tw);
+  }
+
+  PFB_DEV void run_overlap(const KernelParams& p, float2* lds) {
+    long long run = blockIdx.x;
+    if (p.xcd_remap) {
+      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
+      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
+    }
+    const long long f_begin = run * p.frames_per_block;
+    if (f_begin >= p.frames) return;
+    const long long f_last = f_begin + p.frames_per_block;
+    const long long f_end = f_last < p.frames ? f_last : p.frames;
+    Consts k;
+    setup(p, threadIdx.x, k);
+    const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_last <= p.frames);
+    if (interior) run_overlap_impl<true>(p, k, lds, f_begin, f_end);
+    else run_overlap_impl<false>(p, k, lds, f_begin, f_end);
   }
 
   // ---- schedule T: FIR team + FFT team (large M) --------------------------------------------------------
@@ -1893,6 +2013,15 @@ __global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_fast_kernel(const Ker
 }
 
 template <class K>
+__global__ void __launch_bounds__(K::NT, (K::MIN_WAVES > 2 ? K::MIN_WAVES - 1 : K::MIN_WAVES)) pfb_overlap_kernel(const KernelParams p) {
+  __shared__ float2 lds[2 * K::BUF];
+  FastKernel<K>::run_overlap(p, lds);
+}
+
+template <class K>
+constexpr bool kOverlapOk = K::NT == 64 && K::NP == 2 && !K::PINGPONG;
+
+template <class K>
 __global__ void __launch_bounds__(K::NT, (K::MIN_WAVES > 3 ? 3 : K::MIN_WAVES)) pfb_strided_kernel(const KernelParams p) {
   __shared__ float2 lds[K::LDS_ELEMS];
   FastKernel<K>::run_strided(p, lds);
@@ -2153,6 +2282,13 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
         if (p.tile_waves >= 8) return launch_pairs_sliding<K, 8, 4>(p, s);
       }
       return launch_pairs_sliding<K, 6, 3>(p, s);
+    }
+  }
+  if constexpr (kOverlapOk<K>) {  // sliding runs, FIR of the next chunk scheduled into the FFT of this one
+    if (p.schedule == 11) {
+      const long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
+      hipLaunchKernelGGL(pfb_overlap_kernel<K>, dim3((unsigned)nb), dim3(K::NT), 0, s, p);
+      return hipGetLastError();
     }
   }
   if constexpr (kTeamsOk<K>) {  // FIR team + FFT team

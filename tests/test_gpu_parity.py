@@ -439,7 +439,8 @@ def test_large_stream_interior_windows(oracle, M, P, D, fmt, bw, log2n):
                                   {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 4, L.PFB_OPT_FRAMES_PER_BLOCK: 32},
                                   {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 16, L.PFB_OPT_FRAMES_PER_BLOCK: 24,
                                    L.PFB_OPT_XCD_REMAP: 0},
-                                  {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_FRAMES_PER_BLOCK: 24}])
+                                  {L.PFB_OPT_SCHEDULE: 3, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_FRAMES_PER_BLOCK: 24},
+                                  {L.PFB_OPT_SCHEDULE: 11}, {L.PFB_OPT_SCHEDULE: 11, L.PFB_OPT_FRAMES_PER_BLOCK: 40}])
 def test_every_schedule_gives_identical_bits(oracle, opts):
     """The schedules only change which wave computes which frames, never the arithmetic."""
     M, P = 64, 12
@@ -597,6 +598,28 @@ def test_pairs_over_sliding_runs_give_identical_bits(M, P, D, fmt, bw, pairs):
             ch.reset()
             ch.set_option(L.PFB_OPT_SCHEDULE, 7)
             ch.set_option(L.PFB_OPT_TILE_WAVES, pairs)
+            ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, fpb)
+            cut = D * 1777 + 5
+            got = np.concatenate([ch(iq[:cut]), ch(iq[cut:])])
+            assert np.array_equal(got, ref), fpb
+
+
+@pytest.mark.parametrize("M,P,D,fmt,bw", [(128, 12, 64, "int16", 12), (256, 8, 256, "int8", 8), (256, 8, 256, "int16", 12),
+                                          (56, 12, 56, "int16", 12), (56, 12, 56, "int8", 8), (32, 12, 32, "int16", 12),
+                                          (64, 12, 64, "int8", 8), (64, 16, 64, "int16", 12)])
+def test_software_pipelined_runs_give_identical_bits(M, P, D, fmt, bw):
+    """schedule 11: sliding runs with the next chunk's FIR scheduled into this chunk's FFT (two LDS chunk buffers, rows two
+    chunks ahead): runs of one chunk, runs that end mid-chunk, calls cut mid-frame -- the bits of schedule 0."""
+    n = D * 5003 + 11
+    iq = synth.pulsed_iq_numpy(n, bw, np.int8 if fmt == "int8" else np.int16, seed=19)
+    h = np.random.default_rng(14).standard_normal(M * P).astype(np.float32) / M
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, derotate=(D != M), fftshift=True) as ch:
+        ch.set_option(L.PFB_OPT_SCHEDULE, 0)
+        ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, 512)
+        ref = ch(iq)
+        for fpb in (8, 32, 52, 512):
+            ch.reset()
+            ch.set_option(L.PFB_OPT_SCHEDULE, 11)
             ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, fpb)
             cut = D * 1777 + 5
             got = np.concatenate([ch(iq[:cut]), ch(iq[cut:])])
