@@ -77,12 +77,23 @@ PFB_DEV v2f cmul_w(v2f a, v2f w) {
 }
 // acc += x * h.lo / h.hi (tap broadcast to both halves by op_sel): two taps share one register pair,
 // which the compiler will not do by itself (it materialises a splat pair per tap)
-PFB_DEV void fma_tap_lo(v2f& acc, v2f x, v2f h) {
+PFB_DEV void fma_tap_lo(v2f& acc, v2f x, v2f h, int& tok) {
+  (void)tok;
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(h));
 }
-PFB_DEV void fma_tap_hi(v2f& acc, v2f x, v2f h) {
+PFB_DEV void fma_tap_hi(v2f& acc, v2f x, v2f h, int& tok) {
+  (void)tok;
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(h));
 }
+// The same FMAs as builtins: the broadcast is a shufflevector of the tap PAIR, which the backend folds into op_sel /
+// op_sel_hi (checked in the ISA: no v_mov, one v_pk_fma_f32 per tap).  Inline asm hides the instruction from the
+// scheduler: it clusters the FMAs of one accumulator, and on gfx950 the result of a packed-fp32 instruction cannot be read
+// by the very next VALU instruction, so the hazard recognizer pads every such pair with an s_nop (118 per 250 FMAs in the
+// cfg5 loop, 4 issue cycles each; 75 with the builtins, the rest sit in the FFT's cmul_w).  As builtins the scheduler
+// interleaves the C accumulators itself -- at the price of longer live ranges: every other kernel spills with them
+// (cfg2's pair kernel 6 registers, cfg3 36, the cfg4 teams 74), so only the software-pipelined cfg5 kernel takes them.
+PFB_DEV void fma_tap_lo_b(v2f& acc, v2f x, v2f h) { acc = __builtin_elementwise_fma(x, __builtin_shufflevector(h, h, 0, 0), acc); }
+PFB_DEV void fma_tap_hi_b(v2f& acc, v2f x, v2f h) { acc = __builtin_elementwise_fma(x, __builtin_shufflevector(h, h, 1, 1), acc); }
 PFB_DEV v2f add_j(v2f a, v2f b) { return fma2(swp(b), (v2f){-1.f, 1.f}, a); }  // a + j b
 PFB_DEV v2f sub_j(v2f a, v2f b) { return fma2(swp(b), (v2f){1.f, -1.f}, a); }  // a - j b
 
@@ -491,6 +502,11 @@ struct FastKernel {
         const long long f = f0 + fc;
         if (active && f < p_frames) {
           const bool flip_odd = (OS == 2) && (p.flags & PFB_FLAG_DEROTATE) && ((p.frame0 + f) & 1);
+          // derotation of the 2x oversampled bank = a sign on the odd channels of odd frames.  As ONE multiply by a
+          // per-lane +-1 (exact, -0 included); `if (flip) v = -v` per store compiled to a negate, a nop and four
+          // v_cndmask in front of every store, flag set or not: 14 % of the cfg5 kernel's VALU instructions
+          const v2f sg0 = splat((flip_odd && (kk & 1)) ? -1.f : 1.f), sg1 = splat((flip_odd && ((kk + KK) & 1)) ? -1.f : 1.f);
+          auto derot = [&](v2f v, int k) { return OS == 2 ? v * (((k * KK) & 1) ? sg1 : sg0) : v; };
           const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
           // fftshift(out,2): column (k + M/2) mod M.  For a power-of-two M that swaps the two halves of
           // the row, and since KK * R == M the butterfly outputs k < R/2 land in one half and k >= R/2 in
@@ -527,7 +543,7 @@ struct FastKernel {
               if (mag) {
                 *reinterpret_cast<float*>(ptr) = sqrtf(v.x * v.x + v.y * v.y);
               } else {
-                if (flip_odd && ((kk + k * KK) & 1)) v = -v;
+                v = derot(v, k);
                 store_c64(reinterpret_cast<float2*>(ptr), v, p.nontemporal);
               }
               asm volatile("" : "+v"(ptr) : : "memory");
@@ -546,10 +562,7 @@ struct FastKernel {
             // lane exchange a correct layout needs (4 DPP moves per pair): not store-issue-bound, left alone)
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-              const int ch = kk + k * KK;
-              v2f v = x[k];
-              if (flip_odd && (ch & 1)) v = -v;
-              store_c64(slot(row, k), v, p.nontemporal);
+              store_c64(slot(row, k), derot(x[k], k), p.nontemporal);
             }
           }
         }
@@ -600,12 +613,13 @@ struct FastKernel {
       Dft<R>::run(x[it]);
       if (active) {
         const bool flip_odd = (OS == 2) && (p.flags & PFB_FLAG_DEROTATE) && ((p.frame0 + f0 + fc) & 1);
+        const v2f sg0 = splat((flip_odd && (kk & 1)) ? -1.f : 1.f), sg1 = splat((flip_odd && ((kk + KK) & 1)) ? -1.f : 1.f);
         int col = kk + shift;
         if (col >= M) col -= M;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
           v2f v = x[it][k];
-          if (flip_odd && ((kk + k * KK) & 1)) v = -v;
+          if constexpr (OS == 2) v = v * (((k * KK) & 1) ? sg1 : sg0);  // derotation sign, one multiply (see pass<>)
           t2[col * C + tslot_frame(col, fc)] = v;
           col += KK;
           if (col >= M) col -= M;
@@ -682,13 +696,14 @@ struct FastKernel {
         v2f acc[C];  // C independent chains: tap-major order keeps dependent pk_fma's C issues apart
 #pragma unroll
         for (int t = 0; t < C; ++t) acc[t] = (v2f){0.f, 0.f};
+        int tok = 0;  // FMA ordering token (fma_tap_lo)
 #pragma unroll
         for (int q = 0; q < P; ++q) {
           const int j = ph + OS * q;
 #pragma unroll
           for (int t = 0; t < C; ++t) {
-            if (j & 1) fma_tap_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
-            else fma_tap_lo(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+            if (j & 1) fma_tap_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
+            else fma_tap_lo(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
           }
         }
         if (!(K::LANES < NT) || tid < K::LANES) {
@@ -723,13 +738,14 @@ struct FastKernel {
         v2f acc[C];
 #pragma unroll
         for (int t = 0; t < C; ++t) acc[t] = (v2f){0.f, 0.f};
+        int tok = 0;  // FMA ordering token (fma_tap_lo)
 #pragma unroll
         for (int q = 0; q < P; ++q) {
           const int j = ph + OS * q;
 #pragma unroll
           for (int t = 0; t < C; ++t) {
-            if (j & 1) fma_tap_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
-            else fma_tap_lo(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+            if (j & 1) fma_tap_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
+            else fma_tap_lo(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
           }
         }
         if (!(K::LANES < NT) || tid < K::LANES) {
@@ -814,6 +830,7 @@ struct FastKernel {
   // butterflies, LDS writes on the other of two chunk buffers), so the compiler's scheduler can fill the LDS round trips
   // with the next chunk's FMAs; the branch outputs wait in registers and go to LDS after pass 1.  Rows are fetched two
   // chunks ahead instead of one.  Same arithmetic per output as schedule A: bit-identical.
+  static constexpr bool kBuiltinFir = OS == 2 && CPT == 1;  // cfg5's shape: no spills with the scheduler-visible FMAs (see fma_tap_lo_b)
   PFB_DEV void fir_compute(const Consts& k, const v2f (&x)[NW][CPT], v2f (&acc)[OS][CPT][C]) {
 #pragma unroll
     for (int ph = 0; ph < OS; ++ph)
@@ -821,13 +838,19 @@ struct FastKernel {
       for (int cc = 0; cc < CPT; ++cc) {
 #pragma unroll
         for (int t = 0; t < C; ++t) acc[ph][cc][t] = (v2f){0.f, 0.f};
+        int tok = 0;  // FMA ordering token (fma_tap_lo)
 #pragma unroll
         for (int q = 0; q < P; ++q) {
           const int j = ph + OS * q;
 #pragma unroll
           for (int t = 0; t < C; ++t) {
-            if (j & 1) fma_tap_hi(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
-            else fma_tap_lo(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+            if constexpr (kBuiltinFir) {
+              if (j & 1) fma_tap_hi_b(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+              else fma_tap_lo_b(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+            } else {
+              if (j & 1) fma_tap_hi(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
+              else fma_tap_lo(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
+            }
           }
         }
       }
@@ -1917,12 +1940,13 @@ struct SegKernel {
       v2f acc[C];
 #pragma unroll
       for (int t = 0; t < C; ++t) acc[t] = (v2f){0.f, 0.f};
+      int tok = 0;  // FMA ordering token (fma_tap_lo)
 #pragma unroll
       for (int q = 0; q < P; ++q)
 #pragma unroll
         for (int t = 0; t < C; ++t) {
-          if (q & 1) fma_tap_hi(acc[t], x[W - 1 + t - q], hp[q >> 1]);
-          else fma_tap_lo(acc[t], x[W - 1 + t - q], hp[q >> 1]);
+          if (q & 1) fma_tap_hi(acc[t], x[W - 1 + t - q], hp[q >> 1], tok);
+          else fma_tap_lo(acc[t], x[W - 1 + t - q], hp[q >> 1], tok);
         }
       if (lane_on) {
 #pragma unroll
