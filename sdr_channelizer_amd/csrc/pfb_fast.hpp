@@ -2359,6 +2359,8 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       const int key = p.tile_waves * 1000 + p.frames_per_block;
       if (key == 8024) return launch_shared<K, 8, 24>(p, s);
       if (key == 8032) return launch_shared<K, 8, 32>(p, s);
+      if (key == 8064) return launch_shared<K, 8, 64>(p, s);
+      if (key == 4064) return launch_shared<K, 4, 64>(p, s);
       if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64 && K::P == 12) {  // tuning sweep set (cfg2 only, keeps build time sane)
         switch (key) {
           case 4032: return launch_shared<K, 4, 32>(p, s);
