@@ -175,3 +175,20 @@ def test_two_rank_record_sharding_gathers_every_records_pdws_in_file_order():
         assert [c for _, c in listing] == [1, 2, 3, 4, 5]
         assert np.array_equal(allp["toa"], np.repeat(np.arange(5), np.arange(1, 6)))
         assert np.array_equal(allp["bin"], np.repeat(np.arange(5) % world, np.arange(1, 6)))  # who processed which record
+
+
+@pytest.mark.timeout(180)
+def test_bench_starts_its_own_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` outside torch.distributed.run (how the driver ran N = 1 in round 1): the parent starts two
+    fresh rank processes before touching torch.  Here there is no GPU, so both ranks fail -- and the parent must report that
+    and exit non-zero promptly instead of hanging in a collective or printing a line."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--log2-samples", "20",
+                        "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=150, env=env)
+    assert r.returncode != 0
+    assert "ranks failed" in r.stderr and r.stdout.strip() == ""
