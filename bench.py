@@ -343,6 +343,15 @@ def main() -> None:
             copy_bps = L.C.c_double()
             copy_rc = L.load().pfb_measure_stream_copy(local_rank, 1 << 30, 10, L.C.byref(copy_bps))
             res["roofline"]["measured_stream_copy_gbs"] = round(copy_bps.value / 1e9, 1) if copy_rc == 0 else None
+            # ---- what a copy kernel with NO arithmetic reaches for each byte mix, by wave lifetime (rows of 256 B per wave):
+            # the bound the fractions above and below are to be read against
+            bounds = {}
+            for ratio in (2, 4):
+                for spw in (2, 8, 512):
+                    bps = L.C.c_double()
+                    if L.load().pfb_measure_mix_copy(local_rank, 1 << 30, ratio, spw, 5, L.C.byref(bps)) == 0:
+                        bounds[f"1_read_{ratio}_written_{spw}_rows_per_wave"] = round(bps.value / 1e9 / HBM_PEAK_GBS, 4)
+            res["roofline"]["copy_kernel_frac_by_byte_mix"] = bounds
         prefix = iq[: 1 << 28].cpu().numpy() if (world == 1 and not args.no_cpu_baseline and fmt == "int16") else None
         ch.release()
         del iq, out
@@ -371,6 +380,21 @@ def main() -> None:
                                    "kernel_ms": round(oms, 4), "achieved": round(ogbs, 1), "frac": round(ogbs / HBM_PEAK_GBS, 4),
                                    "ms_value": round((1 << olog2) / (oms * 1e-3) / 1e6, 1),
                                    "algorithmic_bytes_per_sample": ob, "launches_timed": 20})
+                    if name == "cfg5" and not cm:
+                        # config 5 end to end (create_pdws_channelized.m:57-143): the matrix just written -> PDWs, device-resident
+                        from sdr_channelizer_amd.pdw import extract_pdws
+                        F5 = (1 << olog2) // oD
+                        y5 = oout[:F5]
+                        extract_pdws(y5, synth.FS, 915e6, 0.0, decimation=oD)  # warm-up: scratch arenas
+                        tp = []
+                        for _ in range(3):
+                            torch.cuda.synchronize(dev)
+                            tq = time.perf_counter()
+                            pd = extract_pdws(y5, synth.FS, 915e6, 0.0, decimation=oD)
+                            tp.append((time.perf_counter() - tq) * 1e3)
+                        others[-1]["end_to_end"] = {"what": "channelizer kernel + PDW extraction of its matrix (host wall, results on the host)",
+                                                    "pdw_extraction_ms": round(min(tp), 3), "pulses": int(len(pd)),
+                                                    "total_ms": round(oms + min(tp), 3)}
                     och.release()
                     del oiq, oout
                     torch.cuda.empty_cache()

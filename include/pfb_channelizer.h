@@ -279,6 +279,13 @@ const char* pfb_last_kernel(const pfb_handle* h);
  * rows per wave, one 16-byte store per lane), so the figure is a yardstick no channelizer kernel
  * with this byte mix should beat. */
 int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double* bytes_per_sec);
+/* The same for either byte mix of the channelizer and a given wave lifetime: a copy kernel with no arithmetic that
+ * reads bytes_in and writes write_ratio x bytes_in (2: int16 I/Q -> complex64 at D = M; 4: int8 I/Q, or int16 at D = M/2),
+ * every wave owning rows_per_wave consecutive 256-byte rows (even, >= 2).  What the memory system gives that byte mix
+ * depends on how short-lived the waves are (0.78 / 0.75 of the nominal 8 TB/s at 2 rows, 0.63 / 0.64 at 512): the
+ * bound bench.py prints next to each shape's fraction. */
+int pfb_measure_mix_copy(int device_id, uint64_t bytes_in, uint32_t write_ratio, uint32_t rows_per_wave, int iters,
+                         double* bytes_per_sec);
 
 /* Page-locked host memory for the sample and output buffers of PFB_MEM_HOST calls -- what the
  * recorders would use in place of `new std::complex<std::int16_t>[n]`

@@ -1245,4 +1245,44 @@ int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double*
   });
 }
 
+int pfb_measure_mix_copy(int device_id, uint64_t bytes_in, uint32_t write_ratio, uint32_t rows_per_wave, int iters,
+                         double* bytes_per_sec) {
+  return pfb::abi_guard([&]() -> int {
+  if (!bytes_per_sec || iters < 1 || (write_ratio != 2 && write_ratio != 4) || rows_per_wave < 2 || (rows_per_wave & 1))
+    return PFB_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return PFB_ERR_NO_DEVICE;
+  }
+  int dev = device_id;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  DeviceGuard g(dev);
+  const long long rows = (long long)(bytes_in / 256) / (4ll * rows_per_wave) * (4ll * rows_per_wave);  // whole workgroups
+  if (rows <= 0) return PFB_ERR_BAD_ARG;
+  void *in = nullptr, *out = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = PFB_OK;
+  float ms = 0.f;
+  hipError_t e = hipMalloc(&in, (size_t)rows * 256);
+  if (e == hipSuccess) e = hipMalloc(&out, (size_t)rows * 256 * write_ratio);
+  if (e == hipSuccess) e = hipMemset(in, 1, (size_t)rows * 256);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = pfb::launch_mix_copy(in, out, rows, (int)write_ratio, (int)rows_per_wave, nullptr);  // warm-up
+  if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+  for (int i = 0; i < iters && e == hipSuccess; ++i) e = pfb::launch_mix_copy(in, out, rows, (int)write_ratio, (int)rows_per_wave, nullptr);
+  if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (e != hipSuccess) rc = hip_fail(e, "pfb_measure_mix_copy");
+  else *bytes_per_sec = (double)rows * 256.0 * (1.0 + write_ratio) * iters / ((double)ms * 1e-3);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(in);
+  (void)hipFree(out);
+  return rc;
+  });
+}
+
 }  // extern "C"

@@ -118,6 +118,7 @@ hipError_t launch_update_history(const void* old_hist, const void* in, long long
 hipError_t launch_transpose_slab(const void* slab, long long frames, int M, void* out, long long out_ld,
                                  long long out_frame0, int elem_bytes, hipStream_t s);
 hipError_t launch_stream_copy(const void* in, void* out, long long n_vec16, hipStream_t s);
+hipError_t launch_mix_copy(const void* in, void* out, long long rows, int write_ratio, int spw, hipStream_t s);
 extern int g_transpose_probe;
 extern int g_transpose_tile_frames;  // frames per tile of the slab transposer: 64, 128 or 256
 

@@ -273,6 +273,33 @@ hipError_t launch_stream_copy(const void* in, void* out, long long n_vec16, hipS
   return hipGetLastError();
 }
 
+// Copy kernels of the channelizer's byte mixes with NO arithmetic (tools/membench6 in the library, so that bench.py can
+// print the bound next to every shape's fraction): each wave owns `spw` consecutive 256-byte rows of the input (one dword
+// per lane and row) and writes RATIO x 256 bytes per row with 16-byte stores; 4-wave workgroups in dispatch order.
+template <int RATIO>
+__global__ void __launch_bounds__(256) pfb_mix_copy_kernel(const unsigned* in, uint4* out, long long rows, int spw) {
+  const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const long long r0 = wv * spw;
+  if (r0 >= rows) return;
+  for (int s = 0; s < spw; s += 2) {  // two rows per step: 512 B in, RATIO x 512 B out
+    const unsigned a = in[(r0 + s) * 64 + lane], b = in[(r0 + s + 1) * 64 + lane];
+    uint4* o = out + (r0 + s) * 16 * RATIO + lane;
+#pragma unroll
+    for (int j = 0; j < RATIO / 2; ++j) o[j * 64] = make_uint4(a, a + j, b, b + j);
+  }
+}
+
+hipError_t launch_mix_copy(const void* in, void* out, long long rows, int write_ratio, int spw, hipStream_t s) {
+  if (rows <= 0 || spw < 2 || (spw & 1) || rows % spw) return hipErrorInvalidValue;
+  const long long waves = rows / spw;
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  if (write_ratio == 4) hipLaunchKernelGGL(pfb_mix_copy_kernel<4>, grid, block, 0, s, (const unsigned*)in, (uint4*)out, rows, spw);
+  else if (write_ratio == 2) hipLaunchKernelGGL(pfb_mix_copy_kernel<2>, grid, block, 0, s, (const unsigned*)in, (uint4*)out, rows, spw);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------
 // fused-kernel table, part 1: the M = 64 shapes (cfg2 and its int8 / cf32 siblings)
 //                 M    P   D  CPT FMT               C NP R0 R1 R2 RS0 RS1 RS2 FS  PP     MINW  TW_TABLE
