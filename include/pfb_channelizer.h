@@ -201,8 +201,8 @@ uint64_t pfb_shard_head_frames(const pfb_handle* h);
 /* Where the predecessor's tail lands (device memory owned by the handle, pfb_halo_samples() samples
  * of cfg.sample_format): what the library passes to the callback as d_recv. */
 void* pfb_halo_recv_buffer(pfb_handle* h);
-/* Channelize this rank's segment (device pointers; num_samples a multiple of D, at least
- * pfb_shard_head_frames()+1 frames, carried tail empty).  Enqueued, no host sync:
+/* Channelize this rank's segment (device pointers; num_samples a multiple of D and at least
+ * pfb_history_samples(), carried tail empty).  Enqueued, no host sync:
  *   side stream : the halo exchange (the callback), ordered behind what the handle's stream has queued
  *   main stream : frames [head, F) -- every frame whose window lies inside the segment -- start at
  *                 once; frames [0, head) follow when the halo has landed (one event wait on the GPU).

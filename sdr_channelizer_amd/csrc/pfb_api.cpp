@@ -1009,7 +1009,9 @@ int pfb_process_shard_async(pfb_handle* h, const void* d_seg, uint64_t n, void* 
   if (h->phase != 0 || n % (uint64_t)h->D != 0) return PFB_ERR_BAD_ARG;
   const uint64_t F = n / (uint64_t)h->D, head = pfb_shard_head_frames(h);
   if (frames_out) *frames_out = F;
-  if (F <= head) return PFB_ERR_BAD_ARG;  // the segment must at least hold its own head frames' windows
+  // a segment shorter than its head frames has no interior: everything waits for the halo; it must still hold the tail
+  // the next shard needs (and the history the handle keeps)
+  if (F == 0 || n < (uint64_t)h->hist_samples) return PFB_ERR_BAD_ARG;
   if (F > cap) return PFB_ERR_CAPACITY;
   if (!d_out) return PFB_ERR_BAD_ARG;
   DeviceGuard g(h->device);
@@ -1035,13 +1037,14 @@ int pfb_process_shard_async(pfb_handle* h, const void* d_seg, uint64_t n, void* 
     HIP_TRY(hipEventRecord(h->ev_halo, h->s_halo));
   }
   // main stream: every frame whose window lies inside the segment starts now ...
-  int rc = launch_frames(h, d_seg, n, nullptr, d_out, head, F, (int64_t)F, 0);
+  const uint64_t nhead = head < F ? head : F;
+  int rc = launch_frames(h, d_seg, n, nullptr, d_out, nhead, F, (int64_t)F, 0);
   if (rc != PFB_OK) return rc;
   // ... the head frames once the halo has landed (a wait on the GPU, not on the host); a shard that receives
   // nothing continues from the handle's own state.  Waiting for the event also puts the SEND in front of
   // whatever the caller queues next on this stream, so pfb_sync() covers both transfers.
   if (sending || receiving) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_halo, 0));
-  rc = launch_frames(h, d_seg, n, receiving ? h->d_halo : h->d_hist[h->cur], d_out, 0, head, (int64_t)F, 0);
+  rc = launch_frames(h, d_seg, n, receiving ? h->d_halo : h->d_hist[h->cur], d_out, 0, nhead, (int64_t)F, 0);
   if (rc != PFB_OK) return rc;
   return advance_state(h, d_seg, n, F);
   });

@@ -137,12 +137,18 @@ def test_ring_shard_continues_the_previous_batch_and_updates_state():
 def test_shard_call_rejects_what_it_cannot_shard():
     import torch
     M, P = 64, 12
-    h = np.zeros(M * P, np.float32)
+    h = np.random.default_rng(5).standard_normal(M * P).astype(np.float32)
     with Channelizer(M, taps=h, bit_width=12) as ch:
         ch.attach_shard(0, 1)
-        short = torch.zeros((ch.shard_head_frames * M, 2), dtype=torch.int16, device="cuda")
-        with pytest.raises(L.PfbError):   # a segment must be longer than its head frames
+        short = torch.zeros((ch.history_samples - M, 2), dtype=torch.int16, device="cuda")
+        with pytest.raises(L.PfbError):   # a segment must at least hold the history the next shard and the handle need
             ch.process_shard(short)
+        # ... but one that is all "head" (no frame without the halo in its window) is fine: it equals a plain call
+        iq = synth.pulsed_iq_numpy(ch.shard_head_frames * M, 12, np.int16, seed=2)
+        want = ch(iq)
+        ch.reset()
+        assert np.array_equal(ch.process_shard(torch.from_numpy(iq).cuda()).cpu().numpy(), want)
+        ch.reset()
         with pytest.raises(ValueError):   # whole frames only
             ch.process_shard(torch.zeros((M * 100 + 1, 2), dtype=torch.int16, device="cuda"))
         ch(np.zeros((7, 2), np.int16))    # a carried tail: no longer on a frame boundary
