@@ -110,10 +110,10 @@ def test_segment_bounds():
     assert all((e - s) % 8 == 0 for s, e in b)
 
 
-@pytest.mark.timeout(120)
-@pytest.mark.parametrize("mode", ["p2p", "allgather"])
-def test_two_rank_time_sharding_matches_single_stream(mode):
-    world, total = 2, D * 400
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("mode,world", [("p2p", 2), ("allgather", 2), ("p2p", 3), ("allgather", 4)])
+def test_two_rank_time_sharding_matches_single_stream(mode, world):
+    total = D * 400
     taps = np.random.default_rng(0).standard_normal(M * P)
     mgr = mp.Manager()
     ret = mgr.dict()
@@ -127,8 +127,10 @@ def test_two_rank_time_sharding_matches_single_stream(mode):
     assert np.array_equal(sharded, single)  # raw-sample halo => identical bits
     for r in range(world):  # ring: each rank holds its predecessor's tail
         assert np.array_equal(ret[r][1], ret[(r - 1) % world][2])
-    # open chain: rank 0 continued from its own (zero) state, rank 1 from exactly (P-1)*M... = M*P - D samples of rank 0
-    assert not ret[0][3].any() and np.array_equal(ret[1][3], ret[0][2]) and ret[1][3].shape[0] == M * P - D
+    # open chain: rank 0 continued from its own (zero) state, rank r from exactly M*P - D samples of rank r - 1
+    assert not ret[0][3].any()
+    for r in range(1, world):
+        assert np.array_equal(ret[r][3], ret[r - 1][2]) and ret[r][3].shape[0] == M * P - D
 
 
 def _folder_worker(rank, world, port, paths, ret):
