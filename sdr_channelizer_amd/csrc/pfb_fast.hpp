@@ -1334,10 +1334,11 @@ struct FastKernel {
   // Here wave w < NPAIR slides the window and writes branch outputs for run w into one of two LDS
   // buffers while wave w + NPAIR transforms and stores the chunk before it: each role needs far fewer
   // registers, so more waves fit per SIMD.  One workgroup barrier per chunk hands the buffers over.
-  template <bool INTERIOR, int NPAIR, int L>
+  template <bool INTERIOR, int NPAIR, int L, int DEPTH = 1>
   PFB_DEV void paired_fir_role(const KernelParams& p, float2* bufs, raw_t* halo_mine, const raw_t* halo_next,
                                int pair, long long f_begin) {
     constexpr int TAIL0 = L - (W - 1), NCH = L / C;
+    static_assert(DEPTH == 1 || DEPTH == 2, "chunks of rows in flight");
     const int tid = threadIdx.x & 63;
     const int c0 = tid * CPT;
     Consts k;
@@ -1345,7 +1346,7 @@ struct FastKernel {
     const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
     const bool lane_on = !(K::LANES < NT) || tid < K::LANES;
     v2f x[NW][CPT];
-    raw_t raw[C][CPT];
+    raw_t raw[DEPTH][C][CPT];
 #pragma unroll
     for (int i = 0; i < W - 1; ++i) {
       raw_t t[CPT];
@@ -1356,10 +1357,18 @@ struct FastKernel {
         if constexpr (INTERIOR) { if (lane_on) halo_mine[i * D + c0 + cc] = t[cc]; }
       }
     }
-#pragma unroll
-    for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + t, W - 1 + t, c0, raw[t]);
-    __syncthreads();  // A: halo slots published
     const bool tail_from_lds = INTERIOR && (pair < NPAIR - 1);
+    auto fetch = [&](int cj) {  // rows of chunk cj (those not coming from the neighbour's halo slot) into raw[cj % DEPTH]
+#pragma unroll
+      for (int t = 0; t < C; ++t) {
+        const int r = cj * C + t;
+        if (!(r >= TAIL0 && tail_from_lds)) load_row<INTERIOR>(p, run_ptr, f_begin + r, W - 1 + r, c0, raw[cj % DEPTH][t]);
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (d < NCH) fetch(d);
+    __syncthreads();  // A: halo slots published
 #pragma unroll
     for (int ci = 0; ci < NCH; ++ci) {
 #pragma unroll
@@ -1371,16 +1380,10 @@ struct FastKernel {
             x[W - 1 + t][cc] = cvt(halo_next[(r - TAIL0) * D + (lane_on ? c0 + cc : 0)]);
         } else {
 #pragma unroll
-          for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);
+          for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[ci % DEPTH][t][cc]);
         }
       }
-      if (ci + 1 < NCH) {
-#pragma unroll
-        for (int t = 0; t < C; ++t) {
-          const int r = (ci + 1) * C + t;
-          if (!(r >= TAIL0 && tail_from_lds)) load_row<INTERIOR>(p, run_ptr, f_begin + r, W - 1 + r, c0, raw[t]);
-        }
-      }
+      if (ci + DEPTH < NCH) fetch(ci + DEPTH);
       fir_to_lds(k, x, bufs + (ci & 1) * K::BUF, tid);
 #pragma unroll
       for (int i = 0; i < W - 1; ++i)
@@ -1411,6 +1414,7 @@ struct FastKernel {
     if (fir_role) {
       raw_t* halo_mine = lds_halo + pair * ((W - 1) * D);
       const raw_t* halo_next = lds_halo + (pair + 1) * ((W - 1) * D);
+      // (DEPTH = 2, rows two chunks ahead, measured on cfg2: 2.255 vs 2.243 ms -- no gain, 126 VGPRs; one chunk ahead stays)
       if (interior) paired_fir_role<true, NPAIR, L>(p, bufs, halo_mine, halo_next, pair, f_begin);
       else paired_fir_role<false, NPAIR, L>(p, bufs, halo_mine, halo_next, pair, f_begin);
     } else {
