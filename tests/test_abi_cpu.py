@@ -165,3 +165,28 @@ def test_fft_plan_model_covers_the_registered_plans():
         R = tuple(int(v) for v in a[7:7 + NP])
         RS = tuple(int(v) for v in a[10:10 + NP])
         assert (M, R, RS, int(a[13])) in modelled, args
+
+
+def test_headers_compile_as_plain_c(tmp_path):
+    """The boundary is a C ABI: both headers must be valid C99 (the recorders are C++, MATLAB's loadlibrary parses C) and
+    a C program must link against the library without a C++ runtime of its own."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi_c.c"
+    src.write_text('#include "pfb_channelizer.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '  pfb_config cfg; pfb_shard_config sc; pfb_pdw w; pfb_iq_info info; double f[8];\n'
+                   '  (void)cfg; (void)sc; (void)w; (void)info;\n'
+                   '  if (pfb_abi_version() != PFB_ABI_VERSION) return 1;\n'
+                   '  if (pfb_center_frequencies_ordered(8, 8e6, PFB_FREQ_ORDER_CENTERED, f) != PFB_OK || f[0] != -4e6) return 2;\n'
+                   '  if (pfb_selftest_exception_guard(0) != PFB_ERR_NO_MEMORY) return 3;\n'
+                   '  printf("%s\\n", pfb_strerror(PFB_ERR_COMM));\n  return 0;\n}\n')
+    exe = tmp_path / "abi_c"
+    libdir = os.path.dirname(L.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L" + libdir, "-lpfb_channelizer", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "halo exchange" in r.stdout, (r.returncode, r.stdout, r.stderr)
