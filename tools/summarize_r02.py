@@ -14,7 +14,7 @@ ALG = {"cfg2": (1 << 30) * 12, "cfg3": (1 << 30) * 10, "cfg4": (1 << 30) * 12, "
 
 
 def channelizer_kernel(name):
-    return "pfb" in name and any(k in name for k in ("paired", "fast_kernel", "teams", "pairs_sliding", "seg_kernel", "tile"))
+    return "pfb" in name and any(k in name for k in ("paired", "fast_kernel", "teams", "pairs_sliding", "seg_kernel", "tile", "overlap"))
 
 
 print("## default bench run under rocprofv3 --kernel-trace --stats")
