@@ -52,7 +52,7 @@ static const FastEntry kRows[] = {
     // runs: cfg5 1.125 -> 1.048 ms per 2^28 samples (59.6 -> 64.0 % of roofline), cfg3 2.104 -> 2.073 ms (63.8 -> 64.8 %)
     entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 64, 11),
     entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 32, 11),
-    entry<Cfg256x8i16>("pfb_fast<M256,P8,D256,int16>", 32, 0),
+    entry<Cfg256x8i16>("pfb_fast<M256,P8,D256,int16>", 32, 11),
     entry<Cfg32x12i16>("pfb_fast<M32,P12,D32,int16>", 512, 0),
     seg_entry<Cfg16x12i16>("pfb_fast<M16,P12,D16,int16>", 1024),
     seg_entry<Cfg8x12i16>("pfb_fast<M8,P12,D8,int16>", 1024),
