@@ -264,3 +264,45 @@ def test_cpp_host_shards_over_every_gpu_with_rccl(tmp_path):
     r = subprocess.run([exe, "8192"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bit-identical to one device" in r.stdout
+
+
+def test_distinct_handles_are_independent_across_host_threads(oracle):
+    """The boundary's threading contract: a handle is single-caller, distinct handles are
+    independent.  Four host threads, each with its own handle (different shapes) and its own stream of chunked calls plus a
+    PDW extraction (whose device scratch is shared behind a mutex): every thread gets what a lone sequential run gets."""
+    import threading
+    from sdr_channelizer_amd.pdw import extract_pdws
+    shapes = [(64, 12, 64, "int16", 12), (128, 12, 64, "int16", 12), (256, 8, 256, "int8", 8), (56, 12, 56, "int16", 12)]
+    work, want = [], []
+    for i, (M, P, D, fmt, bw) in enumerate(shapes):
+        iq = synth.pulsed_iq_numpy(D * 3000 + 7, bw, np.int8 if fmt == "int8" else np.int16, seed=100 + i)
+        h = oracle.design_prototype(M, P).astype(np.float32)
+        work.append((M, P, D, fmt, bw, iq, h))
+        with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, fftshift=True) as ch:
+            y = ch(iq)
+        want.append((y, extract_pdws(y, 56e6, 1e9, 0.0, decimation=D)))
+    got, errors = [None] * len(work), []
+
+    def run(i):
+        try:
+            M, P, D, fmt, bw, iq, h = work[i]
+            with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, fftshift=True) as ch:
+                parts = []
+                for rep in range(3):  # the same stream three times over, in uneven pieces
+                    ch.reset()
+                    cuts = [0, D * 700 + 3, D * 1900, iq.shape[0]]
+                    parts = [ch(iq[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+                y = np.concatenate(parts)
+                got[i] = (y, extract_pdws(y, 56e6, 1e9, 0.0, decimation=D))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(work))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(len(work)):
+        assert np.array_equal(got[i][0], want[i][0]), i
+        assert np.array_equal(got[i][1], want[i][1]), i
