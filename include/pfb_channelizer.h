@@ -254,9 +254,13 @@ typedef enum pfb_option {
                                 /* 7 = a FIR wave + an FFT wave per long sliding run;            */
                                 /* channel-major handles: 0 / 2 as above, 8 = short runs whose   */
                                 /* output is transposed in LDS, 9 = frame-major slabs + a        */
-                                /* transpose kernel, 10 = the team kernel with its output tiles  */
-                                /* transposed through an L2-resident scratch (the default of the */
-                                /* M = 1024 / 560 plans; PFB_OPT_TILE_WAVES 16 = 16-frame tiles) */
+                                /* transpose kernel (the default of the M = 1024 / 560 plans),   */
+                                /* 10 = the team kernel with its output tiles transposed through */
+                                /* a per-workgroup scratch (same                                 */
+                                /* M = 1024 / 560 plans: measured slower than 9, opt-in);        */
+                                /* frame-major again: 11 = 0 software-pipelined inside the wave  */
+                                /* (next chunk's FIR scheduled into this chunk's FFT; the        */
+                                /* default of M = 128 D = 64 and M = 256)                        */
   PFB_OPT_GRID = 7,             /* schedules 1/5: workgroups to launch (0 = all that are resident) */
   PFB_OPT_TILE_WAVES = 8,       /* schedules 2/3: waves, 4/5/7: wave pairs per workgroup         */
   PFB_OPT_EXPERIMENT = 9,       /* bit mask of timing experiments; 0 in production               */

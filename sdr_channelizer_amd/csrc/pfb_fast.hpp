@@ -41,6 +41,10 @@
 //   8 (C') channel-major only: short sliding runs, each chunk transposed in its LDS buffer, the workgroup's
 //          tile written as 256-512-byte runs per channel       (channel-major default of the single-wave plans)
 //   9      channel-major only, host side (pfb_api.cpp): frame-major slabs + pfb_transpose_slab_kernel
+//  10 (T') channel-major only: T with resident workgroups whose FFT waves transpose finished 32-frame tiles out of a
+//          per-workgroup scratch (bit-identical, slower than 9: opt-in)
+//  11 (P)  A software-pipelined inside the wave: next chunk's FIR next to this chunk's first FFT pass, two LDS chunk
+//          buffers, rows two chunks ahead                      (cfg5 / M = 256 default)
 #pragma once
 
 #include "pfb_common.h"
