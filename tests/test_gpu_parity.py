@@ -396,7 +396,8 @@ def test_bench_stream_prefix_of_2e20_samples(oracle, M, P, D, fmt, bw):
     assert rel(y, want) < REL_TOL
 
 
-@pytest.mark.parametrize("M,P,D,fmt,bw,log2n", [(64, 12, 64, "int16", 12, 30), (64, 12, 64, "int16", 12, 31), (256, 8, 256, "int8", 8, 30),
+@pytest.mark.parametrize("M,P,D,fmt,bw,log2n", [(64, 12, 64, "int16", 12, 30), (64, 12, 64, "int16", 12, 31), (64, 12, 64, "int16", 12, 33),
+                                                (256, 8, 256, "int8", 8, 30),
                                                 (1024, 16, 1024, "int16", 16, 28), (128, 12, 64, "int16", 12, 28),
                                                 (56, 12, 56, "int16", 12, 26), (560, 12, 560, "int16", 12, 26)])
 def test_large_stream_interior_windows(oracle, M, P, D, fmt, bw, log2n):
@@ -405,6 +406,9 @@ def test_large_stream_interior_windows(oracle, M, P, D, fmt, bw, log2n):
     windows on pulses -- with the oracle evaluated on just the samples those frames depend on."""
     import torch
     n = 1 << log2n
+    need = n * (2 if fmt == "int8" else 4) + (n // D) * M * 8
+    if torch.cuda.mem_get_info()[0] < need * 1.3:
+        pytest.skip(f"needs {need >> 30} GiB of HBM")
     h = oracle.design_prototype(M, P).astype(np.float32)
     iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device="cuda")
     with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw) as ch:
@@ -424,7 +428,8 @@ def test_large_stream_interior_windows(oracle, M, P, D, fmt, bw, log2n):
         want = oracle_run(oracle, seg, h, M, P, D, bw)[-nwin:]
         got = y[f0:f0 + nwin].cpu().numpy()
         assert np.abs(got - want).max() / max(np.abs(want).max(), 0.05) < REL_TOL, f0
-    assert bool(torch.isfinite(torch.view_as_real(y)).all())
+    for part in y.split(max(1, (1 << 28) // M)):
+        assert bool(torch.isfinite(torch.view_as_real(part)).all())
     del y, iq
     torch.cuda.empty_cache()
 
