@@ -42,8 +42,8 @@ constexpr int kCountingMedian = 512; // cached pulses up to this long take the O
 constexpr int kSampleRows = 65536; // rows sampled to bracket the median (below 8x this the full select runs)
 constexpr int kSamplePasses = 3;   // digits resolved on the sample: bracket edges to 2^-12 relative
 constexpr int kUndecided = 1 << 20; // samples too close to the threshold's bracket to classify before the median is known
-constexpr int kStage = 64;         // LDS staging slots per channel and workgroup in the bracket pass
 constexpr int kBracketRows = 1024; // rows per workgroup of the bracket pass
+constexpr int kBracketInFlight = 16; // rows each lane of the bracket pass has in flight
 constexpr double kRadToDeg = 57.295779513082320876798154814105;
 
 // |y|^2 of a complex64 is EXACT in float64 (two 48-bit products, 49-bit sum), so selecting on it is
@@ -76,58 +76,72 @@ __device__ __forceinline__ void hist_add(unsigned* h, unsigned digit, bool pred)
   else if (pred && digit != d0) atomicAdd(&h[digit], 1u);
 }
 
-// k-th smallest of n doubles produced by get(i), by 8 passes of 8-bit digits; the whole workgroup
-// cooperates (every thread must call it, with the same n and k).  The digit holding rank k is found by
-// wave 0: four counters per lane, a shuffle scan, one lane owns the answer.
-template <class Get>
-__device__ double block_select(Get get, long long n, long long k, unsigned* hist /* [256] shared */,
-                               unsigned long long* pick /* [2] shared */, int first_pass = 0,
-                               unsigned long long prefix = 0ull /* the first_pass digits every value shares */) {
-  for (int pass = first_pass; pass < 8; ++pass) {
+// one wave: the digit of a 256-bin histogram that holds rank k (0 <= k < total count) -> pick[0], and the count of
+// everything in lower digits -> pick[1].  Four counters per lane, a shuffle scan, one lane owns the answer.
+__device__ __forceinline__ void find_digit(const unsigned* hist, unsigned long long k, unsigned long long* pick) {
+  const int l = threadIdx.x & 63;
+  const unsigned long long c0 = hist[4 * l], c1 = hist[4 * l + 1], c2 = hist[4 * l + 2], c3 = hist[4 * l + 3];
+  const unsigned long long sum = c0 + c1 + c2 + c3;
+  unsigned long long inc = sum;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long prev = __shfl_up(inc, d);
+    if (l >= d) inc += prev;
+  }
+  unsigned long long cum = inc - sum;
+  if (cum <= k && k < inc) {  // exactly one lane
+    int d = 4 * l;
+    if (k >= cum + c0) { cum += c0; ++d;
+      if (k >= cum + c1) { cum += c1; ++d;
+        if (k >= cum + c2) { cum += c2; ++d; } } }
+    pick[0] = (unsigned long long)d;
+    pick[1] = cum;
+  }
+}
+
+// k-th smallest of n 64-bit keys produced by getkey(i), by passes of 8-bit digits first_pass .. end_pass-1 (most
+// significant digit = pass 0); the whole workgroup cooperates (every thread must call it, with the same n and k).
+// The digit holding rank k is found by wave 0: four counters per lane, a shuffle scan, one lane owns the answer.
+// Returns the key's digits decided so far (lower bits zero); k becomes the rank inside the last bucket, whose
+// size is still in hist[last digit] on return.
+template <int INFLIGHT = 4, class GetKey>
+__device__ unsigned long long block_select_key(GetKey getkey, long long n, long long& k, unsigned* hist /* [256] shared */,
+                                               unsigned long long* pick /* [2] shared */, int first_pass = 0,
+                                               unsigned long long prefix = 0ull /* the first_pass digits decided so far */,
+                                               int end_pass = 8, bool all_share = true /* every value has those digits */) {
+  for (int pass = first_pass; pass < end_pass; ++pass) {
     const int shift = 56 - 8 * pass;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0u;
     __syncthreads();
-    for (long long i0 = 0; i0 < n; i0 += 4ll * blockDim.x) {  // uniform trip count: hist_add uses wave-wide votes
-      unsigned long long key[4];
-      bool in[4];
+    for (long long i0 = 0; i0 < n; i0 += (long long)INFLIGHT * blockDim.x) {  // uniform trip count: hist_add uses wave-wide votes
+      unsigned long long key[INFLIGHT];
+      bool in[INFLIGHT];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {  // four values in flight per thread
+      for (int u = 0; u < INFLIGHT; ++u) {  // values in flight per thread
         const long long i = i0 + (long long)u * blockDim.x + threadIdx.x;
         in[u] = i < n;
-        key[u] = in[u] ? dkey(get(i)) : 0ull;
+        key[u] = in[u] ? getkey(i) : 0ull;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < INFLIGHT; ++u)
         hist_add(hist, (unsigned)(key[u] >> shift) & 255u,
-                 in[u] && (pass == first_pass || (key[u] >> (shift + 8)) == (prefix >> (shift + 8))));
+                 in[u] && (pass == 0 || (pass == first_pass && all_share) || (key[u] >> (shift + 8)) == (prefix >> (shift + 8))));
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
-      const int l = threadIdx.x;
-      const unsigned long long c0 = hist[4 * l], c1 = hist[4 * l + 1], c2 = hist[4 * l + 2], c3 = hist[4 * l + 3];
-      const unsigned long long sum = c0 + c1 + c2 + c3;
-      unsigned long long inc = sum;
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long prev = __shfl_up(inc, d);
-        if (l >= d) inc += prev;
-      }
-      unsigned long long cum = inc - sum;
-      const unsigned long long kk = (unsigned long long)k;
-      if (cum <= kk && kk < inc) {  // exactly one lane: 0 <= k < n = total count
-        int d = 4 * l;
-        if (kk >= cum + c0) { cum += c0; ++d;
-          if (kk >= cum + c1) { cum += c1; ++d;
-            if (kk >= cum + c2) { cum += c2; ++d; } } }
-        pick[0] = (unsigned long long)d;
-        pick[1] = cum;
-      }
-    }
+    if (threadIdx.x < 64) find_digit(hist, (unsigned long long)k, pick);
     __syncthreads();
     prefix |= pick[0] << shift;
     k -= (long long)pick[1];
     __syncthreads();
   }
-  return dkey_inv(prefix);
+  return prefix;
+}
+
+// k-th smallest of n doubles produced by get(i): all eight digits of the order-preserving key
+template <class Get>
+__device__ double block_select(Get get, long long n, long long k, unsigned* hist /* [256] shared */,
+                               unsigned long long* pick /* [2] shared */, int first_pass = 0,
+                               unsigned long long prefix = 0ull) {
+  return dkey_inv(block_select_key([&](long long i) { return dkey(get(i)); }, n, k, hist, pick, first_pass, prefix));
 }
 
 // MATLAB median.  For an even count the lower middle value is the largest value below the upper one,
@@ -225,35 +239,42 @@ __global__ void __launch_bounds__(256) pdw_hist_kernel(const float2* y, long lon
   }
 }
 
-// rank[0..M) = lo, rank[M..2M) = hi: the two sample ranks of the bracket (no host buffer, no sync)
-__global__ void pdw_fill_ranks_kernel(unsigned long long* rank, int M, unsigned long long lo, unsigned long long hi) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 2 * M) rank[i] = i < M ? lo : hi;
-}
-
 // thr = noise floor * 10^(SNR/10) on the device, so the edge stage can be queued before the host has seen the medians
 __global__ void pdw_thr_kernel(const double* nf, double gain, double* thr, int M) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < M) thr[i] = nf[i] * gain;
 }
 
-// choose the digit holding rank[col]; one thread per column
-__global__ void pdw_pick_kernel(int M, int pass, unsigned* hist, unsigned long long* prefix,
-                                unsigned long long* rank, unsigned* bucket, unsigned long long* below) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+// choose the digit holding rank[col]; one wave per column (four counters per lane, a shuffle scan, one lane owns
+// the answer), four columns per workgroup
+__global__ void __launch_bounds__(256) pdw_pick_kernel(int M, int pass, unsigned* hist, unsigned long long* prefix,
+                                                       unsigned long long* rank, unsigned* bucket, unsigned long long* below) {
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
   if (col >= M) return;
   unsigned* hc = hist + (size_t)col * 256;
-  unsigned long long r = rank[col], cum = 0;
-  int d = 0;
-  for (; d < 255; ++d) {
-    if (cum + hc[d] > r) break;
-    cum += hc[d];
+  const uint4 c4 = *reinterpret_cast<const uint4*>(hc + 4 * l);
+  const unsigned long long c0 = c4.x, c1 = c4.y, c2 = c4.z, c3 = c4.w, sum = c0 + c1 + c2 + c3;
+  unsigned long long inc = sum;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long prev = __shfl_up(inc, d);
+    if (l >= d) inc += prev;
   }
-  prefix[col] |= (unsigned long long)d << (56 - 8 * pass);
-  rank[col] = r - cum;        // rank inside the chosen bucket
-  below[col] += cum;          // elements strictly below the bucket so far
-  bucket[col] = hc[d];
-  for (int i = 0; i < 256; ++i) hc[i] = 0u;
+  unsigned long long cum = inc - sum;
+  const unsigned long long r = rank[col];
+  // the lane whose counters hold rank r; a rank past the total (cannot happen: r < count) would fall to digit 255
+  const bool last = (l == 63) && r >= inc;
+  if ((cum <= r && r < inc) || last) {
+    int d = 4 * l;
+    unsigned cnt = (unsigned)c0;
+    if (r >= cum + c0) { cum += c0; ++d; cnt = (unsigned)c1;
+      if (r >= cum + c1) { cum += c1; ++d; cnt = (unsigned)c2;
+        if (r >= cum + c2) { cum += c2; ++d; cnt = (unsigned)c3; } } }
+    prefix[col] |= (unsigned long long)d << (56 - 8 * pass);
+    rank[col] = r - cum;        // rank inside the chosen bucket
+    below[col] += cum;          // elements strictly below the bucket so far
+    bucket[col] = cnt;
+  }
+  *reinterpret_cast<uint4*>(hc + 4 * l) = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // gather the bucket's exact values, and the largest value below the bucket (for the lower median)
@@ -322,105 +343,277 @@ __global__ void __launch_bounds__(256) pdw_median_finish_kernel(long long F, int
 
 // ---- sampled bracket path -------------------------------------------------------------------------
 
+// The sampled rows are read ONCE: the top 32 bits of every sampled |y|^2 key (the sample decides kSamplePasses = 3
+// digits = 24 bits) go to keys[channel][sample], transposed through LDS so that the per-channel select streams them.
+// grid = (column groups of 64, sample blocks of 64 rows); sixteen far-apart rows in flight per lane.
+__global__ void __launch_bounds__(256) pdw_sample_gather_kernel(const float2* y, long long ns, long long stride, int M,
+                                                                unsigned* keys, long long ld) {
+  __shared__ unsigned tile[64][65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const long long q0 = (long long)blockIdx.y * 64;
+  float2 v[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const long long q = q0 + wave * 16 + u;
+    v[u] = (col < M && q < ns) ? y[sample_row(q, stride) * M + col] : make_float2(0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) tile[wave * 16 + u][lane] = (unsigned)(dkey(mag2_of(v[u])) >> 32);
+  __syncthreads();
+  for (int c = wave; c < 64; c += 4) {
+    const int gc = blockIdx.x * 64 + c;
+    const long long q = q0 + lane;
+    if (gc < M && q < ns) keys[(size_t)gc * ld + q] = tile[lane][c];
+  }
+}
+
+// both bracket ranks of one channel's sample, kSamplePasses digits each; one workgroup per channel.  The channel's
+// keys (ns <= 1024 * kSampleKeysPerThread, guaranteed by F >= 8 * kSampleRows) are read once into registers; every
+// pass counts both selects (two histograms), wave 0 and wave 1 find their digits side by side.
+constexpr int kSampleKeysPerThread = 72;
+static_assert(1024ll * kSampleKeysPerThread >= (long long)kSampleRows * 9 / 8, "ns < kSampleRows * (stride + 1) / stride, stride >= 8");
+__global__ void __launch_bounds__(1024) pdw_sample_select_kernel(const unsigned* keys, long long ns, long long ld,
+                                                                 unsigned long long rank_lo, unsigned long long rank_hi,
+                                                                 unsigned long long* pre_lo, unsigned long long* pre_hi) {
+  __shared__ unsigned hist[2][256];
+  __shared__ unsigned long long pick[2][2];
+  const uint4* k4 = reinterpret_cast<const uint4*>(keys + (size_t)blockIdx.x * ld);
+  constexpr int kQuads = kSampleKeysPerThread / 4;
+  uint4 kq[kQuads];
+#pragma unroll
+  for (int j = 0; j < kQuads; ++j) {
+    const long long q = (long long)j * 1024 + threadIdx.x;
+    kq[j] = (q * 4 < ld) ? k4[q] : make_uint4(0u, 0u, 0u, 0u);
+  }
+  unsigned pre[2] = {0u, 0u};                       // decided digits of the two 32-bit key prefixes
+  unsigned long long rk[2] = {rank_lo, rank_hi};
+#pragma unroll 1
+  for (int pass = 0; pass < kSamplePasses; ++pass) {
+    const int shift = 24 - 8 * pass;
+    for (int i = threadIdx.x; i < 512; i += 1024) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    const unsigned hmask = pass ? ~0u << (shift + 8) : 0u;  // the digits already decided
+#pragma unroll
+    for (int j = 0; j < kQuads; ++j) {
+      const long long base = ((long long)j * 1024 + threadIdx.x) * 4;
+      const unsigned kk[4] = {kq[j].x, kq[j].y, kq[j].z, kq[j].w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool valid = base + u < ns;
+        const unsigned digit = (kk[u] >> shift) & 255u;
+        hist_add(hist[0], digit, valid && (kk[u] & hmask) == pre[0]);
+        hist_add(hist[1], digit, valid && (kk[u] & hmask) == pre[1]);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) find_digit(hist[threadIdx.x >> 6], rk[threadIdx.x >> 6], pick[threadIdx.x >> 6]);
+    __syncthreads();
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+      pre[z] |= (unsigned)pick[z][0] << shift;
+      rk[z] -= pick[z][1];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    pre_lo[blockIdx.x] = (unsigned long long)pre[0] << 32;
+    pre_hi[blockIdx.x] = (unsigned long long)pre[1] << 32;
+  }
+}
+
 // One pass over the data with the bracket [lo, hi] of every channel (key prefixes from the sample, low
-// bits cleared / set): count and track the maximum of what lies below, gather what lies inside.
-// Candidates are staged per workgroup in LDS (lane = channel) and flushed as contiguous runs, so the
-// global append costs one atomic per channel and workgroup; a full stage spills element by element.
+// bits cleared / set): count what lies below, gather what lies inside.
 //
 // The same pass writes the edge machine's comparison masks.  The threshold is gain * median, and the
 // median lies in [sqrt(lo), sqrt(hi)], so |y|^2 below lo * gain^2 is certainly under the threshold and
 // above hi * gain^2 certainly over it (both with a 1e-9 guard band); the few samples in between are
 // listed and classified exactly once the median is known (pdw_patch_kernel).  One word (64 frames)
-// per wave at a time, lane = channel; a workgroup covers kBracketRows frames.
+// per wave at a time, lane = channel.
+//
+// Every sample is SCREENED in float32: m32 = fl(x^2 + y^2) is within 2^-23 of the exact |y|^2, and four
+// per-channel float32 limits set 2^-19 outside lo / hi / t2lo / t2hi tell "surely below the bracket", "surely
+// above it" and "surely over / under the threshold" in a dozen instructions.  A sample inside the bracket's
+// zone (the 2 % candidates plus a 4e-6 wide rim) is parked as it is, 8 bytes, in a staging column that belongs
+// to its (wave, lane, channel) -- a register counts the slots, no atomics -- and the float64 classification
+// (below / inside / above, exactly as the unscreened pass did) happens once per workgroup when the columns are
+// flushed: one channel per wave at a time, lanes = (source wave, slot), candidates appended as one contiguous
+// run per channel.  A full column (16 slots; ~5 expected) classifies on the spot.  Samples inside the
+// threshold's zone are a handful: reloaded and classified exactly.  max_below covers the zone only: it is the
+// true maximum below lo whenever it is non-zero, and the finish kernel asks for a redo in the (never seen)
+// case that needs it and finds it zero.
+__device__ __forceinline__ void bracket_screen(double lo, double hi, float& a, float& b) {
+  if (lo > 1e-30 && hi < 1e30) {  // float32 keeps its relative accuracy here
+    a = (float)(lo * (1.0 - 0x1p-19));
+    b = (float)(hi * (1.0 + 0x1p-19));
+  } else {  // everything is "inside the zone": the exact route decides
+    a = 0.0f;
+    b = INFINITY;
+  }
+}
+
+constexpr int kBracketSlots = 16;  // staging slots per (wave, channel): 4 waves x 16 slots = the 64 lanes of the flush
+
+// grid = (column groups of 64, a few workgroups per CU); a workgroup walks row groups of kBracketRows frames
+// (long-lived workgroups read faster than thousands of short ones), flushing its staging columns after each.
 __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long long F, int M,
                                                           const unsigned long long* pre_lo, const unsigned long long* pre_hi,
                                                           double gain2, double* cand, unsigned cap, unsigned* cand_n,
                                                           unsigned long long* below, unsigned long long* max_below,
                                                           unsigned long long* f0, unsigned long long* f1, long long words,
-                                                          unsigned long long* undecided, unsigned* und_n, unsigned* flags) {
-  __shared__ double stage[kStage][64];
-  __shared__ unsigned cnt[64], base[64];
+                                                          unsigned long long* undecided, unsigned* und_n, unsigned* flags,
+                                                          int row_groups) {
+  __shared__ float2 stage[4][kBracketSlots][64];
+  __shared__ unsigned char cnt[4][64];
+  __shared__ unsigned cand_cnt[64], cand_base[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < 64) cnt[threadIdx.x] = 0u;
-  __syncthreads();
   const int col = blockIdx.x * 64 + lane;
+  const bool valid = col < M;
   constexpr unsigned long long kLow = (1ull << (64 - 8 * kSamplePasses)) - 1ull;
   constexpr int kWordsPerBlock = kBracketRows / 64;
-  if (col < M) {
-    const unsigned long long lo = pre_lo[col] & ~kLow, hi = pre_hi[col] | kLow;
-    const double t2lo = dkey_inv(lo) * gain2 * (1.0 - 1e-9), t2hi = dkey_inv(hi) * gain2 * (1.0 + 1e-9);
-    unsigned long long nb = 0ull, best = 0ull;
-    for (int wi = wave; wi < kWordsPerBlock; wi += 4) {
-      const long long w = (long long)blockIdx.y * kWordsPerBlock + wi;
-      if (w >= words) break;
-      const long long r0 = w * 64;
-      unsigned long long over = 0ull;
-      auto visit = [&](float2 v, int i) {
-        const double m = mag2_of(v);
-        const unsigned long long k = dkey(m);
-        if (k < lo) {
-          ++nb;
-          best = k > best ? k : best;
-        } else if (k <= hi) {
-          const unsigned slot = atomicAdd(&cnt[lane], 1u);
-          if (slot < (unsigned)kStage) {
-            stage[slot][lane] = m;
-          } else {
-            const unsigned g = atomicAdd(&cand_n[col], 1u);
-            if (g < cap) cand[(size_t)col * cap + g] = m;
-            else atomicOr(flags, 1u);
+  const unsigned long long lo = valid ? pre_lo[col] & ~kLow : 0ull, hi = valid ? pre_hi[col] | kLow : 0ull;
+  const double t2lo = dkey_inv(lo) * gain2 * (1.0 - 1e-9), t2hi = dkey_inv(hi) * gain2 * (1.0 + 1e-9);
+  float sA, sB, sC, sD;
+  bracket_screen(dkey_inv(lo), dkey_inv(hi), sA, sB);
+  bracket_screen(t2lo, t2hi, sC, sD);
+  unsigned long long nb = 0ull, best = 0ull;
+  const int ws = lane / kBracketSlots, sl = lane % kBracketSlots;  // the flush's view of a lane
+
+  for (int rg = blockIdx.y; rg < row_groups; rg += gridDim.y) {
+    unsigned n = 0u, nb32 = 0u;
+    if (valid) {
+      for (int wi = wave; wi < kWordsPerBlock; wi += 4) {
+        const long long w = (long long)rg * kWordsPerBlock + wi;
+        if (w >= words) break;
+        const long long r0 = w * 64;
+        unsigned long long over = 0ull;
+        // the float64 route, on the spot: a full staging column, the threshold's zone, the ragged last word
+        auto exact = [&](float2 v, int i, bool for_median, bool for_mask) {
+          const double m = mag2_of(v);
+          if (for_median) {
+            const unsigned long long k = dkey(m);
+            if (k < lo) {
+              ++nb;
+              best = k > best ? k : best;
+            } else if (k <= hi) {
+              const unsigned g = atomicAdd(&cand_n[col], 1u);
+              if (g < cap) cand[(size_t)col * cap + g] = m;
+              else atomicOr(flags, 1u);
+            }
+          }
+          if (for_mask) {
+            if (m > t2hi) {
+              over |= 1ull << i;
+            } else if (m >= t2lo) {
+              const unsigned u = atomicAdd(und_n, 1u);
+              if (u < (unsigned)kUndecided) undecided[u] = (unsigned long long)(r0 + i) * (unsigned long long)M + (unsigned)col;
+              else atomicOr(flags, 4u);
+            }
+          }
+        };
+        unsigned long long pad = 0ull;  // frames past F: identity (f0 = 0, f1 = 1)
+        if (r0 + 64 <= F) {
+          for (int i = 0; i < 64; i += kBracketInFlight) {  // rows in flight per lane
+            float2 v[kBracketInFlight];
+#pragma unroll
+            for (int u = 0; u < kBracketInFlight; ++u) v[u] = y[(r0 + i + u) * M + col];
+            unsigned ov = 0u, ub = 0u, sb = 0u;
+#pragma unroll
+            for (int u = 0; u < kBracketInFlight; ++u) {
+              const float m32 = __fmaf_rn(v[u].x, v[u].x, __fmul_rn(v[u].y, v[u].y));
+              nb32 += (unsigned)(m32 < sA);
+              if (!(m32 < sA) && !(m32 > sB)) {
+                if (n < (unsigned)kBracketSlots) stage[wave][n][lane] = v[u];
+                else sb |= 1u << u;
+                ++n;
+              }
+              ov |= (unsigned)(m32 > sD) << u;
+              ub |= (unsigned)(!(m32 < sC) && !(m32 > sD)) << u;
+            }
+            over |= (unsigned long long)ov << i;
+            unsigned bits = ub | sb;
+            while (bits) {  // the threshold's zone, a full column: reload (the line is in cache) and classify exactly
+              const int u = __ffs((int)bits) - 1;
+              bits &= bits - 1u;
+              exact(y[(r0 + i + u) * M + col], i + u, (sb >> u) & 1u, (ub >> u) & 1u);
+            }
+          }
+        } else {
+          for (int i = 0; i < 64; ++i) {
+            if (r0 + i < F) exact(y[(r0 + i) * M + col], i, true, true);
+            else pad |= 1ull << i;
           }
         }
-        if (m > t2hi) {
-          over |= 1ull << i;
-        } else if (m >= t2lo) {
-          const unsigned u = atomicAdd(und_n, 1u);
-          if (u < (unsigned)kUndecided) undecided[u] = (unsigned long long)(r0 + i) * (unsigned long long)M + (unsigned)col;
-          else atomicOr(flags, 4u);
-        }
-      };
-      unsigned long long pad = 0ull;  // frames past F: identity (f0 = 0, f1 = 1)
-      if (r0 + 64 <= F) {
-        for (int i = 0; i < 64; i += 4) {  // four rows in flight per lane
-          const float2 a = y[(r0 + i) * M + col], b = y[(r0 + i + 1) * M + col], c = y[(r0 + i + 2) * M + col],
-                       d = y[(r0 + i + 3) * M + col];
-          visit(a, i); visit(b, i + 1); visit(c, i + 2); visit(d, i + 3);
-        }
-      } else {
-        for (int i = 0; i < 64; ++i) {
-          if (r0 + i < F) visit(y[(r0 + i) * M + col], i);
-          else pad |= 1ull << i;
-        }
+        f0[w * M + col] = over;
+        f1[w * M + col] = over | pad;
       }
-      f0[w * M + col] = over;
-      f1[w * M + col] = over | pad;
     }
+    nb += nb32;
+    cnt[wave][lane] = (unsigned char)(n < (unsigned)kBracketSlots ? n : (unsigned)kBracketSlots);
+    __syncthreads();
+    // flush: one channel per wave at a time, lane = (source wave, slot); exact classification of the parked samples.
+    // Counting first, then ONE round of appends to the global candidate counters for all the channels at once (a
+    // returning atomic per channel inside the loop would serialise sixteen memory round trips per wave), then the stores.
+    auto classify = [&](int c, int gc, double& m, unsigned long long& k, bool& is_below, bool& is_cand) {
+      const bool has = sl < (int)cnt[ws][c];
+      const unsigned long long klo = pre_lo[gc] & ~kLow, khi = pre_hi[gc] | kLow;
+      const float2 v = has ? stage[ws][sl][c] : make_float2(0.f, 0.f);
+      m = mag2_of(v);
+      k = dkey(m);
+      is_below = has && k < klo;
+      is_cand = has && k >= klo && k <= khi;
+    };
+    for (int c = wave; c < 64; c += 4) {
+      const int gc = blockIdx.x * 64 + c;
+      if (gc >= M) break;
+      double m;
+      unsigned long long k;
+      bool is_below, is_cand;
+      classify(c, gc, m, k, is_below, is_cand);
+      const unsigned long long vb = __ballot(is_below), vc = __ballot(is_cand);
+      if (lane == 0) cand_cnt[c] = (unsigned)__popcll(vc);
+      if (vb) {
+        if (lane == __ffsll((long long)vb) - 1) atomicAdd(&below[gc], (unsigned long long)__popcll(vb));
+        if (is_below) atomicMax(&max_below[gc], k);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int gc = blockIdx.x * 64 + threadIdx.x;
+      cand_base[threadIdx.x] = (gc < M && cand_cnt[threadIdx.x]) ? atomicAdd(&cand_n[gc], cand_cnt[threadIdx.x]) : 0u;
+    }
+    __syncthreads();
+    for (int c = wave; c < 64; c += 4) {
+      const int gc = blockIdx.x * 64 + c;
+      if (gc >= M) break;
+      if (cand_cnt[c] == 0u) continue;  // uniform over the wave
+      double m;
+      unsigned long long k;
+      bool is_below, is_cand;
+      classify(c, gc, m, k, is_below, is_cand);
+      const unsigned long long vc = __ballot(is_cand);
+      if (is_cand) {
+        const unsigned pos = cand_base[c] + (unsigned)__popcll(vc & ((1ull << lane) - 1ull));
+        if (pos < cap) cand[(size_t)gc * cap + pos] = m;
+        else atomicOr(flags, 1u);
+      }
+    }
+    __syncthreads();  // the staging columns are free again
+  }
+  if (valid) {
     if (nb) atomicAdd(&below[col], nb);
     if (best) atomicMax(&max_below[col], best);
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    const unsigned n = cnt[threadIdx.x] < (unsigned)kStage ? cnt[threadIdx.x] : (unsigned)kStage;
-    base[threadIdx.x] = (c < M && n) ? atomicAdd(&cand_n[c], n) : 0u;
-  }
-  __syncthreads();
-  for (int c = wave; c < 64; c += 4) {  // one channel per wave at a time: lanes = slots, contiguous stores
-    const int gc = blockIdx.x * 64 + c;
-    if (gc >= M) break;
-    const unsigned n = cnt[c] < (unsigned)kStage ? cnt[c] : (unsigned)kStage, b = base[c];
-    for (unsigned sl = lane; sl < n; sl += 64) {
-      if (b + sl < cap) cand[(size_t)gc * cap + b + sl] = stage[sl][c];
-      else atomicOr(flags, 1u);
-    }
   }
 }
 
 // exact order statistics among the gathered candidates; one workgroup per channel.  The median's rank
 // must fall inside the candidate set -- that is the proof the sampled bracket held it.  The digits
-// lo and hi share are known, so the select starts below them; the lower middle value of an even count
-// is the largest candidate below the upper one unless that one repeats.  Also checks that the threshold
-// really lies inside the band the provisional masks assumed (flag 8 if not).
+// lo and hi share are known, so the select starts below them: ONE histogram pass over the candidates on the
+// first undecided digit, a second pass that moves that digit's bucket (1/256 of them or so) into LDS, and the
+// remaining digits are decided there.  The lower middle value of an even count is the largest candidate below
+// the upper one unless that one repeats.  Also checks that the threshold really lies inside the band the
+// provisional masks assumed (flag 8 if not).
+constexpr int kFinishLds = 4096;  // bucket members held in LDS; a larger bucket (heavily tied data) keeps selecting in memory
 __global__ void __launch_bounds__(1024) pdw_bracket_finish_kernel(long long F, const double* cand, unsigned cap,
                                                                   const unsigned* cand_n, const unsigned long long* below,
                                                                   const unsigned long long* max_below,
@@ -430,6 +623,8 @@ __global__ void __launch_bounds__(1024) pdw_bracket_finish_kernel(long long F, c
   __shared__ unsigned hist[256];
   __shared__ unsigned long long pick[2];
   __shared__ unsigned long long lt_count, lt_max;
+  __shared__ unsigned long long members[kFinishLds];
+  __shared__ unsigned members_n;
   const int col = blockIdx.x;
   const unsigned long long n = cand_n[col], b = below[col], target = (unsigned long long)(F / 2);
   if (n > cap || b > target || target - b >= n) {  // uniform over the workgroup
@@ -441,29 +636,95 @@ __global__ void __launch_bounds__(1024) pdw_bracket_finish_kernel(long long F, c
   int shared_digits = 0;
   while (shared_digits < 8 && (lo >> (56 - 8 * shared_digits)) == (hi >> (56 - 8 * shared_digits))) ++shared_digits;
   const unsigned long long known = shared_digits ? (lo & (~0ull << (64 - 8 * shared_digits))) : 0ull;
-  const long long r = (long long)(target - b);
+  const long long r0 = (long long)(target - b);  // the upper middle value's rank among the candidates
   const double* v = cand + (size_t)col * cap;
-  auto get = [&](long long i) { return v[i]; };
-  const double v1 = (shared_digits == 8) ? dkey_inv(lo) : block_select(get, (long long)n, r, hist, pick, shared_digits, known);
+  auto getkey = [&](long long i) { return dkey(v[i]); };
+  const bool even = (F & 1) == 0;
+  if (threadIdx.x == 0) { lt_count = 0ull; lt_max = 0ull; members_n = 0u; }
+  unsigned long long k1;
+  bool lower_known = false;  // lt_count / lt_max already hold the candidates below k1
+  if (shared_digits == 8) {
+    k1 = lo;
+  } else {
+    long long r = r0;
+    unsigned long long pfx = known;
+    int pass = shared_digits;  // digits decided so far
+    unsigned bucket = (unsigned)n;
+    while (pass < 8 && bucket > (unsigned)kFinishLds) {  // uniform: passes over all the candidates until the bucket fits LDS
+      pfx = block_select_key<16>(getkey, (long long)n, r, hist, pick, pass, pfx, pass + 1, pass == shared_digits);
+      bucket = hist[(unsigned)(pfx >> (56 - 8 * pass)) & 255u];
+      __syncthreads();
+      ++pass;
+    }
+    if (pass == 8) {
+      k1 = pfx;
+    } else {
+      // move the bucket into LDS (slots claimed per wave), and remember the largest candidate below the bucket
+      const unsigned long long dmask = pass == 0 ? 0ull : ~0ull << (64 - 8 * pass);
+      const int lane = threadIdx.x & 63;
+      unsigned long long mx = 0ull;
+      for (long long i0 = 0; i0 < (long long)n; i0 += 8ll * blockDim.x) {  // uniform trip count: wave-wide votes
+        unsigned long long kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // eight candidates in flight per thread
+          const long long i = i0 + (long long)u * blockDim.x + threadIdx.x;
+          kk[u] = i < (long long)n ? getkey(i) : ~0ull;  // ~0 is neither a member nor below
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const unsigned long long k = kk[u];
+          const bool in = k != ~0ull && (k & dmask) == pfx;
+          if (k != ~0ull && k < pfx) mx = k > mx ? k : mx;
+          const unsigned long long vote = __ballot(in);
+          if (vote) {
+            const int leader = __ffsll((long long)vote) - 1;
+            unsigned base = 0u;
+            if (lane == leader) base = atomicAdd(&members_n, (unsigned)__popcll(vote));
+            base = (unsigned)__shfl((int)base, leader);
+            if (in) members[base + (unsigned)__popcll(vote & ((1ull << lane) - 1ull))] = k;
+          }
+        }
+      }
+      if (mx) atomicMax(&lt_max, mx);
+      __syncthreads();
+      const long long r_in = r;  // rank inside the bucket
+      k1 = block_select_key([&](long long i) { return members[i]; }, (long long)bucket, r, hist, pick, pass, pfx);
+      if (even && r0 > 0) {
+        unsigned long long c = 0ull, m2 = 0ull;
+        for (unsigned i = threadIdx.x; i < bucket; i += blockDim.x) {
+          const unsigned long long k = members[i];
+          if (k < k1) { ++c; m2 = k > m2 ? k : m2; }
+        }
+        if (c) { atomicAdd(&lt_count, c); atomicMax(&lt_max, m2); }  // members outrank everything below the bucket
+        __syncthreads();
+        if (threadIdx.x == 0) lt_count += (unsigned long long)(r0 - r_in);  // candidates in the lower buckets
+        __syncthreads();
+        lower_known = true;
+      }
+    }
+  }
+  const double v1 = dkey_inv(k1);
   double res;
-  if (F & 1) {
+  if (!even) {
     res = sqrt(v1);
   } else {
     double v0;
-    if (r == 0) {
-      v0 = dkey_inv(max_below[col]);
+    if (r0 == 0) {
+      const unsigned long long mb = max_below[col];
+      if (mb == 0ull && threadIdx.x == 0) atomicOr(flags, 2u);  // nothing near the bracket's lower edge was seen exactly: redo
+      v0 = dkey_inv(mb);
     } else {
-      if (threadIdx.x == 0) { lt_count = 0ull; lt_max = 0ull; }
-      __syncthreads();
-      unsigned long long c = 0ull, mx = 0ull;
-      const unsigned long long k1 = dkey(v1);
-      for (long long i = threadIdx.x; i < (long long)n; i += blockDim.x) {
-        const unsigned long long k = dkey(v[i]);
-        if (k < k1) { ++c; mx = k > mx ? k : mx; }
+      if (!lower_known) {
+        __syncthreads();
+        unsigned long long c = 0ull, mx = 0ull;
+        for (long long i = threadIdx.x; i < (long long)n; i += blockDim.x) {
+          const unsigned long long k = getkey(i);
+          if (k < k1) { ++c; mx = k > mx ? k : mx; }
+        }
+        if (c) { atomicAdd(&lt_count, c); atomicMax(&lt_max, mx); }
+        __syncthreads();
       }
-      if (c) { atomicAdd(&lt_count, c); atomicMax(&lt_max, mx); }
-      __syncthreads();
-      v0 = (lt_count == (unsigned long long)r) ? dkey_inv(lt_max) : v1;
+      v0 = (lt_count == (unsigned long long)r0) ? dkey_inv(lt_max) : v1;
     }
     res = 0.5 * (sqrt(v0) + sqrt(v1));
   }
@@ -527,31 +788,32 @@ __global__ void __launch_bounds__(256) pdw_mask_kernel(const float2* y, long lon
   if (only_if && (*only_if & 12u) == 0u) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
-  const long long w = (long long)blockIdx.y * 4 + wave;
-  if (col >= M || w >= words) return;
+  if (col >= M) return;
   const double t = thr[col];
-  const long long r0 = w * 64;
-  unsigned long long a = 0ull, b = 0ull;
-  if (r0 + 64 <= F) {
+  for (long long w = (long long)blockIdx.y * 4 + wave; w < words; w += 4ll * gridDim.y) {  // grid-stride over the words
+    const long long r0 = w * 64;
+    unsigned long long a = 0ull, b = 0ull;
+    if (r0 + 64 <= F) {
 #pragma unroll 8
-    for (int i = 0; i < 64; ++i) {
-      const double m = mag_of(y[(r0 + i) * M + col]);
-      a |= (unsigned long long)(m >= t) << i;
-      b |= (unsigned long long)(m > t) << i;
-    }
-  } else {
-    for (int i = 0; i < 64; ++i) {
-      if (r0 + i < F) {
+      for (int i = 0; i < 64; ++i) {
         const double m = mag_of(y[(r0 + i) * M + col]);
         a |= (unsigned long long)(m >= t) << i;
         b |= (unsigned long long)(m > t) << i;
-      } else {
-        b |= 1ull << i;
+      }
+    } else {
+      for (int i = 0; i < 64; ++i) {
+        if (r0 + i < F) {
+          const double m = mag_of(y[(r0 + i) * M + col]);
+          a |= (unsigned long long)(m >= t) << i;
+          b |= (unsigned long long)(m > t) << i;
+        } else {
+          b |= 1ull << i;
+        }
       }
     }
+    f0[w * M + col] = a;
+    f1[w * M + col] = b;
   }
-  f0[w * M + col] = a;
-  f1[w * M + col] = b;
 }
 
 // tile summaries for BOTH incoming states: fn[tile][col] = f(0) | f(1) << 1 and the edge counts of either
@@ -1135,10 +1397,10 @@ int edges_and_pulses(Src src, int Mi, long long ntiles, int tile_words, const Ed
   const unsigned tblocks = (unsigned)((tm + 255) / 256);
   hipLaunchKernelGGL(pdw_tilefn_kernel, dim3(tblocks), dim3(256), 0, st, (const unsigned long long*)e.f0,
                      (const unsigned long long*)e.f1, Mi, ntiles, tile_words, e.fn, e.cnt);
-  if (Mi >= 32) {
+  if (Mi >= 32 && ntiles < 2048) {
     hipLaunchKernelGGL(pdw_tilescan_kernel<64>, dim3(Mi), dim3(64), 0, st, Mi, ntiles, (const unsigned char*)e.fn,
                        (const ushort4*)e.cnt, e.state, e.off_s, e.off_e, e.tot, e.tot + M);
-  } else {  // few columns: the parallelism has to come from time
+  } else {  // few columns or many tiles per column: the parallelism has to come from time
     hipLaunchKernelGGL(pdw_tilescan_kernel<1024>, dim3(Mi), dim3(1024), 0, st, Mi, ntiles, (const unsigned char*)e.fn,
                        (const ushort4*)e.cnt, e.state, e.off_s, e.off_e, e.tot, e.tot + M);
   }
@@ -1181,13 +1443,15 @@ done:
   return rc;
 }
 
-// Tile length of the edge scan, in words: the scan kernel walks a column's tiles with one workgroup, so
-// long streams get longer tiles (at most 2^14 tiles per column up to 2^30 samples); the per-tile edge counts are 16-bit, which
-// caps a tile at 2^16 samples.
-int tile_words_for(long long samples) {
+// Tile length of the edge scan, in words.  The scan kernel walks a column's tiles with one workgroup (a strided, latency-
+// bound walk), the tile kernels before and after it want >= 2^18 (tile, column) threads: at most 2^18 / M tiles per
+// column, between 2048 and 16384 (measured at M = 128, 2^22 frames: scan + tile kernels 166 us at 8192 tiles per
+// column, 100 us at 2048, 111 us at 1024).  The per-tile edge counts are 16-bit, which caps a tile at 2^16 samples.
+int tile_words_for(long long samples, int M) {
   const long long w = (samples + 63) / 64;
+  const long long max_tiles = std::min<long long>(16384, std::max<long long>(2048, (1ll << 18) / std::max(1, M)));
   int tw = kTileWords;
-  while (tw < 1024 && w / tw > 16384) tw *= 2;
+  while (tw < 1024 && w / tw > max_tiles) tw *= 2;
   return tw;
 }
 
@@ -1229,11 +1493,10 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
   std::lock_guard<std::mutex> lock(g_ws_mutex);  // one extraction per process at a time shares the scratch
   Arena& ws = g_ws[dev][0];
   Arena& ws2 = g_ws[dev][1];
-
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const long long F = (long long)frames;
   const int Mi = (int)M;
-  const int tile_words = tile_words_for(F);
+  const int tile_words = tile_words_for(F, Mi);
   const long long ntiles = (F + 64ll * tile_words - 1) / (64ll * tile_words);
   const long long words = ntiles * tile_words;  // whole tiles; the tail is identity-padded
   const int cgroups = (Mi + 63) / 64;
@@ -1247,9 +1510,10 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
   const long long delta = (long long)std::ceil(2.5 * std::sqrt((double)ns)) + 2;  // 5 sigma of the median's sample rank
   const size_t expect = (size_t)((double)(2 * delta + 1) / (double)ns * (double)F);
   const unsigned cap = sampled ? (unsigned)std::min<size_t>((size_t)F, 2 * expect + 4096) : 0u;
+  const long long key_ld = (ns + 63) / 64 * 64;  // sample keys per channel, padded to whole 256-byte lines
 
   const float2* d_y = nullptr;
-  unsigned *d_hist, *d_bucket, *d_cand_n, *d_flags, *d_und_n;
+  unsigned *d_hist, *d_bucket, *d_cand_n, *d_flags, *d_und_n, *d_keys;
   unsigned long long *d_prefix, *d_prefix_hi, *d_rank, *d_below, *d_maxbelow, *d_und;
   double *d_cand, *d_thr;
   EdgeStage e{};
@@ -1257,6 +1521,7 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
   std::vector<unsigned long long> h_rank(M);
   std::vector<double> h_nf(M), h_binf(M);
   unsigned h_flags = 0;
+  size_t zero_bytes = 0;
   int passes = 0;
   const double gain = std::pow(10.0, snr_threshold_db / 10.0);  // :74-75 (dB applied to magnitude with /10)
   const int row_blocks = (int)std::min<long long>(1024, std::max<long long>(1, F / 256));
@@ -1266,9 +1531,10 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
     size_t need = 0;
     if (mem == PFB_MEM_HOST) need += padded((size_t)F * M * sizeof(float2));
     if (flags & PFB_PDW_CHANNEL_MAJOR) need += padded((size_t)F * M * sizeof(float2));
-    need += padded(2 * (size_t)M * 256 * sizeof(unsigned)) + 2 * padded(2 * M * sizeof(unsigned)) + 2 * padded(sizeof(unsigned));
+    need += padded((size_t)M * 256 * sizeof(unsigned)) + 2 * padded(M * sizeof(unsigned)) + 2 * padded(sizeof(unsigned));
     need += 4 * padded(2 * M * sizeof(unsigned long long)) + padded((size_t)kUndecided * sizeof(unsigned long long));
     need += padded(cand_elems * sizeof(double)) + padded(M * sizeof(double));
+    if (sampled) need += padded((size_t)M * key_ld * sizeof(unsigned));
     need += edge_stage_bytes(words, ntiles, M);
     PDW_TRY(arena_reserve(ws, need));
   }
@@ -1287,57 +1553,56 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
     PDW_TRY(pfb::launch_transpose_slab(d_y, (long long)M, (int)F, fm, (long long)M, 0, (int)sizeof(float2), st));
     d_y = fm;
   }
-  d_hist = take<unsigned>(ws, 2 * (size_t)M * 256);  // [select][channel][digit]; the sample runs two selects at once
-  d_bucket = take<unsigned>(ws, 2 * (size_t)M);
-  d_cand_n = take<unsigned>(ws, 2 * (size_t)M);
-  d_flags = take<unsigned>(ws, 1);
-  d_und_n = take<unsigned>(ws, 1);
+  d_hist = take<unsigned>(ws, (size_t)M * 256);  // [channel][digit] of the full select
+  d_bucket = take<unsigned>(ws, (size_t)M);
   d_prefix = take<unsigned long long>(ws, 2 * (size_t)M);
   d_prefix_hi = d_prefix + M;
-  d_rank = take<unsigned long long>(ws, 2 * (size_t)M);
-  d_below = take<unsigned long long>(ws, 2 * (size_t)M);
-  d_maxbelow = take<unsigned long long>(ws, 2 * (size_t)M);
+  d_rank = take<unsigned long long>(ws, (size_t)M);
+  // zeroed together by one memset (consecutive in the arena): d_below .. d_und_n
+  d_below = take<unsigned long long>(ws, (size_t)M);
+  d_maxbelow = take<unsigned long long>(ws, (size_t)M);
+  d_cand_n = take<unsigned>(ws, (size_t)M);
+  d_flags = take<unsigned>(ws, 1);
+  d_und_n = take<unsigned>(ws, 1);
+  zero_bytes = (size_t)(reinterpret_cast<char*>(d_und_n + 1) - reinterpret_cast<char*>(d_below));
   d_und = take<unsigned long long>(ws, (size_t)kUndecided);
   d_cand = take<double>(ws, cand_elems);
   d_thr = take<double>(ws, M);
+  d_keys = sampled ? take<unsigned>(ws, (size_t)M * key_ld) : nullptr;
   e = take_edge_stage(ws, words, ntiles, M, true);
 
-  PDW_TRY(hipMemsetAsync(d_hist, 0, 2 * (size_t)M * 256 * sizeof(unsigned), st));
   pfb_center_frequencies(M, fs_in, h_binf.data());  // :42, before fs is decimated
   PDW_TRY(hipMemcpyAsync(e.binf, h_binf.data(), M * sizeof(double), hipMemcpyHostToDevice, st));
 
   // ---- noise floor (:73), sampled bracket first.  Everything up to the edge totals is queued without a host sync:
-  // sample selects, the bracket pass (which also leaves provisional masks), the candidate select, thresholds on the
-  // device, the patch of the unclassified samples (or a full mask pass if the device finds the provisional masks
-  // unusable), tile summaries and scan.  The host reads flags, medians and totals in one go.
+  // the sample (gathered once, selected per channel), the bracket pass (which also leaves provisional masks), the
+  // candidate select, thresholds on the device, the patch of the unclassified samples (or a full mask pass if the
+  // device finds the provisional masks unusable), tile summaries and scan.  The host reads flags, medians and totals
+  // in one go.
   if (sampled) {
-    const int sblocks = (int)std::min<long long>(1024, std::max<long long>(1, ns / 1024));  // few, long blocks: the 64 KB LDS histogram's clear and flush dominate a short one
-    PDW_TRY(hipMemsetAsync(d_prefix, 0, 2 * (size_t)M * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(pdw_fill_ranks_kernel, dim3((2 * Mi + 255) / 256), dim3(256), 0, st, d_rank, Mi,
+    PDW_TRY(hipMemsetAsync(d_below, 0, zero_bytes, st));
+    hipLaunchKernelGGL(pdw_sample_gather_kernel, dim3(cgroups, (unsigned)((ns + 63) / 64)), dim3(256), 0, st, d_y, ns, stride, Mi,
+                       d_keys, key_ld);
+    hipLaunchKernelGGL(pdw_sample_select_kernel, dim3(Mi), dim3(1024), 0, st, (const unsigned*)d_keys, ns, key_ld,
                        (unsigned long long)std::max<long long>(0, ns / 2 - delta),
-                       (unsigned long long)std::min<long long>(ns - 1, ns / 2 + delta));
-    for (int ps = 0; ps < kSamplePasses; ++ps) {  // both bracket ranks in the same launches (select 0 = low, 1 = high)
-      hipLaunchKernelGGL(pdw_hist_kernel, dim3(cgroups, sblocks, 2), dim3(256), 0, st, d_y, ns, stride, Mi, ps,
-                         (const unsigned long long*)d_prefix, d_hist);
-      hipLaunchKernelGGL(pdw_pick_kernel, dim3((2 * Mi + 63) / 64), dim3(64), 0, st, 2 * Mi, ps, d_hist, d_prefix, d_rank,
-                         d_bucket, d_below);
+                       (unsigned long long)std::min<long long>(ns - 1, ns / 2 + delta), d_prefix, d_prefix_hi);
+    {
+      const int row_groups = (int)((words * 64 + kBracketRows - 1) / kBracketRows);
+      // many short-lived workgroups (one or two row groups each) beat a few long-lived ones here: 0.83 vs 0.92 ms
+      const int gy = std::max(1, std::min(row_groups, 32 * 256 / cgroups));
+      hipLaunchKernelGGL(pdw_bracket_kernel, dim3(cgroups, gy), dim3(256), 0, st, d_y, F, Mi,
+                         (const unsigned long long*)d_prefix, (const unsigned long long*)d_prefix_hi, gain * gain, d_cand, cap,
+                         d_cand_n, d_below, d_maxbelow, e.f0, e.f1, words, d_und, d_und_n, d_flags, row_groups);
     }
-    PDW_TRY(hipMemsetAsync(d_below, 0, 2 * (size_t)M * sizeof(unsigned long long), st));
-    PDW_TRY(hipMemsetAsync(d_maxbelow, 0, M * sizeof(unsigned long long), st));
-    PDW_TRY(hipMemsetAsync(d_cand_n, 0, M * sizeof(unsigned), st));
-    PDW_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
-    PDW_TRY(hipMemsetAsync(d_und_n, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(pdw_bracket_kernel, dim3(cgroups, (unsigned)((words * 64 + kBracketRows - 1) / kBracketRows)), dim3(256), 0, st,
-                       d_y, F, Mi, (const unsigned long long*)d_prefix, (const unsigned long long*)d_prefix_hi, gain * gain,
-                       d_cand, cap, d_cand_n, d_below, d_maxbelow, e.f0, e.f1, words, d_und, d_und_n, d_flags);
     hipLaunchKernelGGL(pdw_bracket_finish_kernel, dim3(Mi), dim3(1024), 0, st, F, (const double*)d_cand, cap,
                        (const unsigned*)d_cand_n, (const unsigned long long*)d_below, (const unsigned long long*)d_maxbelow,
                        (const unsigned long long*)d_prefix, (const unsigned long long*)d_prefix_hi, gain, e.nf, d_flags);
     hipLaunchKernelGGL(pdw_thr_kernel, dim3((Mi + 255) / 256), dim3(256), 0, st, (const double*)e.nf, gain, d_thr, Mi);
     hipLaunchKernelGGL(pdw_patch_kernel, dim3(64), dim3(256), 0, st, d_y, Mi, (const double*)d_thr,
                        (const unsigned long long*)d_und, (const unsigned*)d_und_n, e.f0, e.f1);
-    hipLaunchKernelGGL(pdw_mask_kernel, dim3(cgroups, (unsigned)((words + 3) / 4)), dim3(256), 0, st, d_y, F, Mi,
-                       (const double*)d_thr, e.f0, e.f1, words, (const unsigned*)d_flags);
+    // (almost always a no-op: few workgroups, each striding over the words when it does run)
+    hipLaunchKernelGGL(pdw_mask_kernel, dim3(cgroups, (unsigned)std::min<long long>((words + 3) / 4, 8192 / cgroups + 1)), dim3(256), 0, st,
+                       d_y, F, Mi, (const double*)d_thr, e.f0, e.f1, words, (const unsigned*)d_flags);
     PDW_TRY(hipGetLastError());
     rc = edges_and_pulses(ChanSrc{d_y, Mi}, Mi, ntiles, tile_words, e, ws2, fs, fc, sample_start_time, flags, out, capacity,
                           count, st, d_flags, &h_flags, h_nf.data());
@@ -1360,7 +1625,7 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
     for (passes = 0; passes < 8;) {
       hipLaunchKernelGGL(pdw_hist_kernel, dim3(cgroups, row_blocks), dim3(256), 0, st, d_y, F, 1ll, Mi, passes, d_prefix,
                          d_hist);
-      hipLaunchKernelGGL(pdw_pick_kernel, dim3((Mi + 63) / 64), dim3(64), 0, st, Mi, passes, d_hist, d_prefix, d_rank,
+      hipLaunchKernelGGL(pdw_pick_kernel, dim3((Mi + 3) / 4), dim3(256), 0, st, Mi, passes, d_hist, d_prefix, d_rank,
                          d_bucket, d_below);
       ++passes;
       PDW_TRY(hipMemcpyAsync(h_bucket.data(), d_bucket, M * sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -1372,7 +1637,7 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
     hipLaunchKernelGGL(pdw_median_finish_kernel, dim3(Mi), dim3(256), 0, st, F, passes, d_cand, d_cand_n, d_prefix, d_rank,
                        d_maxbelow, e.nf);
     hipLaunchKernelGGL(pdw_thr_kernel, dim3((Mi + 255) / 256), dim3(256), 0, st, (const double*)e.nf, gain, d_thr, Mi);
-    hipLaunchKernelGGL(pdw_mask_kernel, dim3(cgroups, (unsigned)((words + 3) / 4)), dim3(256), 0, st, d_y, F, Mi,
+    hipLaunchKernelGGL(pdw_mask_kernel, dim3(cgroups, (unsigned)std::min<long long>((words + 3) / 4, 65535)), dim3(256), 0, st, d_y, F, Mi,
                        (const double*)d_thr, e.f0, e.f1, words, (const unsigned*)nullptr);
     PDW_TRY(hipGetLastError());
     if (noise_floor_out) {
@@ -1507,7 +1772,7 @@ static int pdw_extract_raw_impl(const void* iq, uint64_t num_samples, uint32_t s
   Arena& ws2 = g_ws[dev][1];
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const long long n = (long long)num_samples;
-  const int tile_words = tile_words_for(n);
+  const int tile_words = tile_words_for(n, 1);
   const long long ntiles = (n + 64ll * tile_words - 1) / (64ll * tile_words);
   const long long words = ntiles * tile_words;
   const size_t bps = sample_format == PFB_FMT_INT8_IQ ? 2 : sample_format == PFB_FMT_INT16_IQ ? 4 : 8;

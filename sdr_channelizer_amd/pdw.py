@@ -6,6 +6,7 @@ was found in."""
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -13,6 +14,18 @@ from . import _lib as L
 
 PDW_DTYPE = np.dtype([("toa", "f8"), ("freq", "f8"), ("pw", "f8"), ("snr", "f8"), ("sat", "i4"), ("bin", "i4"),
                       ("mag", "f8")])
+
+
+_tls = threading.local()
+
+
+def _out_buffer(capacity: int):
+    """The landing zone of a call's PDWs: one buffer per thread, kept (and its pages touched) between calls -- a fresh
+    48 MB np.zeros per call costs more than the extraction's host side; callers get a copy of the records found."""
+    buf = getattr(_tls, "out", None)
+    if buf is None or len(buf) < capacity:
+        buf = _tls.out = np.empty(max(int(capacity), 1), dtype=PDW_DTYPE)
+    return buf
 
 
 def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decimation: int | None = None,
@@ -43,7 +56,7 @@ def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decima
         a = np.ascontiguousarray(np.asarray(y), dtype=np.complex64)
         frames, M = a.shape[::-1] if channel_major else a.shape
         ptr, mem, keep, stream = C.c_void_p(a.ctypes.data), L.PFB_MEM_HOST, a, C.c_void_p(0)
-    out = np.zeros(capacity, dtype=PDW_DTYPE)
+    out = _out_buffer(capacity)
     assert out.dtype.itemsize == C.sizeof(L.PfbPdw)
     nf = np.zeros(M, dtype=np.float64)
     count = C.c_uint64(0)
@@ -60,7 +73,7 @@ def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decima
     n = int(count.value)
     if n > capacity:
         raise OverflowError(f"{n} pulses found, capacity {capacity}")
-    return (out[:n], nf) if return_noise_floor else out[:n]
+    return (out[:n].copy(), nf) if return_noise_floor else out[:n].copy()
 
 
 def pdws_from_iq_file(channelizer, path: str, *, snr_threshold_db: float = 15.0, matlab_quirks: bool = True,
@@ -73,7 +86,7 @@ def pdws_from_iq_file(channelizer, path: str, *, snr_threshold_db: float = 15.0,
     lib = L.load()
     if reset:
         channelizer.reset()  # a fresh channelizer per file, create_pdws_channelized.m:33
-    out = np.zeros(capacity, dtype=PDW_DTYPE)
+    out = _out_buffer(capacity)
     nf = np.zeros(channelizer.num_bands, dtype=np.float64)
     count = C.c_uint64(0)
     info = L.PfbIqInfo()
@@ -88,7 +101,7 @@ def pdws_from_iq_file(channelizer, path: str, *, snr_threshold_db: float = 15.0,
     n = int(count.value)
     if n > capacity:
         raise OverflowError(f"{n} pulses found, capacity {capacity}")
-    return (out[:n], nf, info) if return_noise_floor else (out[:n], info)
+    return (out[:n].copy(), nf, info) if return_noise_floor else (out[:n].copy(), info)
 
 
 def raw_pdws_from_iq_file(path: str, *, snr_threshold_db: float = 18.0, trailing_threshold_db: float = 3.0,
@@ -96,7 +109,7 @@ def raw_pdws_from_iq_file(path: str, *, snr_threshold_db: float = 18.0, trailing
     """One iteration of create_pdws.m's loop (pfb_pdw_raw_from_iq_file): the record's raw stream -> PDWs, with fs, fc,
     bit width and start time from its header.  Returns (pdws, info) or (pdws, noise_floor, info)."""
     lib = L.load()
-    out = np.zeros(capacity, dtype=PDW_DTYPE)
+    out = _out_buffer(capacity)
     nf = C.c_double(0.0)
     count = C.c_uint64(0)
     info = L.PfbIqInfo()
@@ -109,7 +122,7 @@ def raw_pdws_from_iq_file(path: str, *, snr_threshold_db: float = 18.0, trailing
     n = int(count.value)
     if n > capacity:
         raise OverflowError(f"{n} pulses found, capacity {capacity}")
-    return (out[:n], nf.value, info) if return_noise_floor else (out[:n], info)
+    return (out[:n].copy(), nf.value, info) if return_noise_floor else (out[:n].copy(), info)
 
 
 def extract_pdws_raw(iq, fs: float, fc: float, sample_start_time: float, *, bit_width: int = 12,
@@ -139,7 +152,7 @@ def extract_pdws_raw(iq, fs: float, fc: float, sample_start_time: float, *, bit_
             raise ValueError("iq must be (n, 2) int8/int16 or (n,) complex64")
         n = int(a.shape[0])
         ptr, mem, keep, stream = C.c_void_p(a.ctypes.data), L.PFB_MEM_HOST, a, C.c_void_p(0)
-    out = np.zeros(capacity, dtype=PDW_DTYPE)
+    out = _out_buffer(capacity)
     assert out.dtype.itemsize == C.sizeof(L.PfbPdw)
     nf = C.c_double(0.0)
     count = C.c_uint64(0)
@@ -154,4 +167,4 @@ def extract_pdws_raw(iq, fs: float, fc: float, sample_start_time: float, *, bit_
     k = int(count.value)
     if k > capacity:
         raise OverflowError(f"{k} pulses found, capacity {capacity}")
-    return (out[:k], nf.value) if return_noise_floor else out[:k]
+    return (out[:k].copy(), nf.value) if return_noise_floor else out[:k].copy()

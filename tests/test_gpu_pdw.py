@@ -118,7 +118,7 @@ def big_matrix(F, M, seed, levels=0):
     return y
 
 
-@pytest.mark.parametrize("F,M,levels,path", [(600000, 24, 0, 1), (600001, 70, 0, 1), (600000, 8, 200, 3)])
+@pytest.mark.parametrize("F,M,levels,path", [(600000, 24, 0, 1), (600001, 70, 0, 1), (600000, 8, 200, 3), (3000000, 6, 0, 1), (2999999, 3, 0, 1)])
 def test_long_streams_take_the_sampled_bracket_and_stay_exact(oracle, F, M, levels, path):
     """F >= 8 * 65536 frames: the noise floor comes from the sampled bracket + one pass (path 1); data too tied
     for the bracket (a coarse amplitude grid) fail its count check and fall back to the full select (path 3).

@@ -22,6 +22,8 @@ for rep in range(4):
     dt = time.perf_counter() - t0
     print(f"PDW extraction: F={y.shape[0]} M={M}: {len(got)} pulses in {dt * 1e3:.1f} ms")
 
+if os.environ.get("PDW_BENCH_SKIP_RAW"):
+    sys.exit(0)
 # raw-stream extraction (create_pdws.m) on the same recorder stream; its pulses stand 14 dB (dB/10) above the floor
 from sdr_channelizer_amd.pdw import extract_pdws_raw  # noqa: E402
 
