@@ -36,7 +36,7 @@ namespace {
 
 constexpr int kTile = 512;        // smallest tile of the edge scan, in frames (tiles grow with the stream, see tile_words_for)
 constexpr int kCand = 2048;       // candidate capacity per channel for the exact median finish
-constexpr int kPulseCache = 1024; // per-pulse values cached in LDS up to this many (channelized: pulses are tens of frames)
+constexpr int kPulseCache = 512;  // per-pulse values cached in LDS up to this many (channelized: pulses are tens of frames)
 constexpr int kPulseCacheRaw = 7168; // same for the raw stream, whose pulses are thousands of samples (56 KB of LDS)
 constexpr int kCountingMedian = 512; // cached pulses up to this long take the O(n^2 / threads) counting median
 constexpr int kSampleRows = 65536; // rows sampled to bracket the median (below 8x this the full select runs)
@@ -98,41 +98,54 @@ __device__ __forceinline__ void find_digit(const unsigned* hist, unsigned long l
   }
 }
 
+// One digit of a radix select over n 64-bit keys produced by getkey(i); the whole workgroup cooperates (every thread
+// must call it, with the same arguments).  The top `db` bits are decided (prefix holds them, lower bits zero); the digit
+// is the next `width` (<= 8) bits.  Keys whose decided bits differ from prefix do not count (all_share: the caller
+// knows that every key has them).  On return prefix has the digit, db has grown by width, k is the rank inside the
+// digit's bucket and hist[digit] is still that bucket's size.  The digit holding rank k is found by wave 0.
+template <int INFLIGHT = 4, class GetKey>
+__device__ void block_digit_pass(GetKey getkey, long long n, long long& k, unsigned* hist /* [256] shared */,
+                                 unsigned long long* pick /* [2] shared */, int& db, int width, unsigned long long& prefix,
+                                 bool all_share) {
+  const int shift = 64 - db - width;
+  const unsigned dmask = (1u << width) - 1u;
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0u;
+  __syncthreads();
+  const bool nofilter = db == 0 || all_share;
+  for (long long i0 = 0; i0 < n; i0 += (long long)INFLIGHT * blockDim.x) {  // uniform trip count: hist_add uses wave-wide votes
+    unsigned long long key[INFLIGHT];
+    bool in[INFLIGHT];
+#pragma unroll
+    for (int u = 0; u < INFLIGHT; ++u) {  // values in flight per thread
+      const long long i = i0 + (long long)u * blockDim.x + threadIdx.x;
+      in[u] = i < n;
+      key[u] = in[u] ? getkey(i) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < INFLIGHT; ++u)
+      hist_add(hist, (unsigned)(key[u] >> shift) & dmask,
+               in[u] && (nofilter || (key[u] >> (64 - db)) == (prefix >> (64 - db))));
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) find_digit(hist, (unsigned long long)k, pick);
+  __syncthreads();
+  prefix |= pick[0] << shift;
+  k -= (long long)pick[1];
+  db += width;
+  __syncthreads();
+}
+
 // k-th smallest of n 64-bit keys produced by getkey(i), by passes of 8-bit digits first_pass .. end_pass-1 (most
-// significant digit = pass 0); the whole workgroup cooperates (every thread must call it, with the same n and k).
-// The digit holding rank k is found by wave 0: four counters per lane, a shuffle scan, one lane owns the answer.
-// Returns the key's digits decided so far (lower bits zero); k becomes the rank inside the last bucket, whose
-// size is still in hist[last digit] on return.
+// significant digit = pass 0).  Returns the key's digits decided so far (lower bits zero); k becomes the rank inside
+// the last bucket, whose size is still in hist[last digit] on return.
 template <int INFLIGHT = 4, class GetKey>
 __device__ unsigned long long block_select_key(GetKey getkey, long long n, long long& k, unsigned* hist /* [256] shared */,
                                                unsigned long long* pick /* [2] shared */, int first_pass = 0,
                                                unsigned long long prefix = 0ull /* the first_pass digits decided so far */,
                                                int end_pass = 8, bool all_share = true /* every value has those digits */) {
-  for (int pass = first_pass; pass < end_pass; ++pass) {
-    const int shift = 56 - 8 * pass;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0u;
-    __syncthreads();
-    for (long long i0 = 0; i0 < n; i0 += (long long)INFLIGHT * blockDim.x) {  // uniform trip count: hist_add uses wave-wide votes
-      unsigned long long key[INFLIGHT];
-      bool in[INFLIGHT];
-#pragma unroll
-      for (int u = 0; u < INFLIGHT; ++u) {  // values in flight per thread
-        const long long i = i0 + (long long)u * blockDim.x + threadIdx.x;
-        in[u] = i < n;
-        key[u] = in[u] ? getkey(i) : 0ull;
-      }
-#pragma unroll
-      for (int u = 0; u < INFLIGHT; ++u)
-        hist_add(hist, (unsigned)(key[u] >> shift) & 255u,
-                 in[u] && (pass == 0 || (pass == first_pass && all_share) || (key[u] >> (shift + 8)) == (prefix >> (shift + 8))));
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) find_digit(hist, (unsigned long long)k, pick);
-    __syncthreads();
-    prefix |= pick[0] << shift;
-    k -= (long long)pick[1];
-    __syncthreads();
-  }
+  int db = 8 * first_pass;
+  for (int pass = first_pass; pass < end_pass; ++pass)
+    block_digit_pass<INFLIGHT>(getkey, n, k, hist, pick, db, 8, prefix, pass == first_pass && all_share);
   return prefix;
 }
 
@@ -394,6 +407,7 @@ __global__ void __launch_bounds__(1024) pdw_sample_select_kernel(const unsigned*
     for (int i = threadIdx.x; i < 512; i += 1024) (&hist[0][0])[i] = 0u;
     __syncthreads();
     const unsigned hmask = pass ? ~0u << (shift + 8) : 0u;  // the digits already decided
+    const bool split = pre[0] != pre[1];  // the two ranks sit in one bucket until their digits part: one histogram serves both
 #pragma unroll
     for (int j = 0; j < kQuads; ++j) {
       const long long base = ((long long)j * 1024 + threadIdx.x) * 4;
@@ -403,11 +417,11 @@ __global__ void __launch_bounds__(1024) pdw_sample_select_kernel(const unsigned*
         const bool valid = base + u < ns;
         const unsigned digit = (kk[u] >> shift) & 255u;
         hist_add(hist[0], digit, valid && (kk[u] & hmask) == pre[0]);
-        hist_add(hist[1], digit, valid && (kk[u] & hmask) == pre[1]);
+        if (split) hist_add(hist[1], digit, valid && (kk[u] & hmask) == pre[1]);  // uniform over the workgroup
       }
     }
     __syncthreads();
-    if (threadIdx.x < 128) find_digit(hist[threadIdx.x >> 6], rk[threadIdx.x >> 6], pick[threadIdx.x >> 6]);
+    if (threadIdx.x < 128) find_digit(hist[split ? threadIdx.x >> 6 : 0], rk[threadIdx.x >> 6], pick[threadIdx.x >> 6]);
     __syncthreads();
 #pragma unroll
     for (int z = 0; z < 2; ++z) {
@@ -479,7 +493,10 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
   unsigned long long nb = 0ull, best = 0ull;
   const int ws = lane / kBracketSlots, sl = lane % kBracketSlots;  // the flush's view of a lane
 
-  for (int rg = blockIdx.y; rg < row_groups; rg += gridDim.y) {
+  for (int rgi = blockIdx.y; rgi < row_groups; rgi += gridDim.y) {
+    // last rows first: when the matrix has just been written (the channelizer ran right before), its tail is still in
+    // the 256 MB Infinity Cache (tools/mall_probe.py: a 256 MB buffer reads back 1.4x faster than a large one)
+    const int rg = row_groups - 1 - rgi;
     unsigned n = 0u, nb32 = 0u;
     if (valid) {
       for (int wi = wave; wi < kWordsPerBlock; wi += 4) {
@@ -555,9 +572,9 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
     // Counting first, then ONE round of appends to the global candidate counters for all the channels at once (a
     // returning atomic per channel inside the loop would serialise sixteen memory round trips per wave), then the stores.
     auto classify = [&](int c, int gc, double& m, unsigned long long& k, bool& is_below, bool& is_cand) {
-      const bool has = sl < (int)cnt[ws][c];
+      const bool has = ws < 4 && sl < (int)cnt[ws < 4 ? ws : 0][c];
       const unsigned long long klo = pre_lo[gc] & ~kLow, khi = pre_hi[gc] | kLow;
-      const float2 v = has ? stage[ws][sl][c] : make_float2(0.f, 0.f);
+      const float2 v = has ? stage[ws < 4 ? ws : 0][sl][c] : make_float2(0.f, 0.f);
       m = mag2_of(v);
       k = dkey(m);
       is_below = has && k < klo;
@@ -607,10 +624,10 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
 }
 
 // exact order statistics among the gathered candidates; one workgroup per channel.  The median's rank
-// must fall inside the candidate set -- that is the proof the sampled bracket held it.  The digits
-// lo and hi share are known, so the select starts below them: ONE histogram pass over the candidates on the
-// first undecided digit, a second pass that moves that digit's bucket (1/256 of them or so) into LDS, and the
-// remaining digits are decided there.  The lower middle value of an even count is the largest candidate below
+// must fall inside the candidate set -- that is the proof the sampled bracket held it.  The leading bits
+// lo and hi share are known, so the select starts right below them: ONE histogram pass over the candidates on the
+// next 8 bits, a second pass that moves that digit's bucket (1/100 of them or so) into LDS, and the
+// remaining bits are decided there.  The lower middle value of an even count is the largest candidate below
 // the upper one unless that one repeats.  Also checks that the threshold really lies inside the band the
 // provisional masks assumed (flag 8 if not).
 constexpr int kFinishLds = 4096;  // bucket members held in LDS; a larger bucket (heavily tied data) keeps selecting in memory
@@ -633,9 +650,7 @@ __global__ void __launch_bounds__(1024) pdw_bracket_finish_kernel(long long F, c
   }
   constexpr unsigned long long kLow = (1ull << (64 - 8 * kSamplePasses)) - 1ull;
   const unsigned long long lo = pre_lo[col] & ~kLow, hi = pre_hi[col] | kLow;
-  int shared_digits = 0;
-  while (shared_digits < 8 && (lo >> (56 - 8 * shared_digits)) == (hi >> (56 - 8 * shared_digits))) ++shared_digits;
-  const unsigned long long known = shared_digits ? (lo & (~0ull << (64 - 8 * shared_digits))) : 0ull;
+  const int shared_bits = lo == hi ? 64 : __clzll((long long)(lo ^ hi));  // leading bits every candidate has
   const long long r0 = (long long)(target - b);  // the upper middle value's rank among the candidates
   const double* v = cand + (size_t)col * cap;
   auto getkey = [&](long long i) { return dkey(v[i]); };
@@ -643,24 +658,26 @@ __global__ void __launch_bounds__(1024) pdw_bracket_finish_kernel(long long F, c
   if (threadIdx.x == 0) { lt_count = 0ull; lt_max = 0ull; members_n = 0u; }
   unsigned long long k1;
   bool lower_known = false;  // lt_count / lt_max already hold the candidates below k1
-  if (shared_digits == 8) {
+  if (shared_bits == 64) {
     k1 = lo;
   } else {
     long long r = r0;
-    unsigned long long pfx = known;
-    int pass = shared_digits;  // digits decided so far
+    int db = shared_bits;  // bits decided so far
+    unsigned long long pfx = db ? lo & (~0ull << (64 - db)) : 0ull;
     unsigned bucket = (unsigned)n;
-    while (pass < 8 && bucket > (unsigned)kFinishLds) {  // uniform: passes over all the candidates until the bucket fits LDS
-      pfx = block_select_key<16>(getkey, (long long)n, r, hist, pick, pass, pfx, pass + 1, pass == shared_digits);
-      bucket = hist[(unsigned)(pfx >> (56 - 8 * pass)) & 255u];
+    // passes over all the candidates until the bucket fits LDS: the 8 bits right below the shared ones spread the
+    // bracket's population over up to 256 buckets, so one pass is the rule
+    while (db < 64 && bucket > (unsigned)kFinishLds) {  // uniform
+      const int width = 64 - db < 8 ? 64 - db : 8;
+      block_digit_pass<16>(getkey, (long long)n, r, hist, pick, db, width, pfx, db == shared_bits);
+      bucket = hist[(unsigned)(pfx >> (64 - db)) & ((1u << width) - 1u)];
       __syncthreads();
-      ++pass;
     }
-    if (pass == 8) {
+    if (db == 64) {
       k1 = pfx;
     } else {
       // move the bucket into LDS (slots claimed per wave), and remember the largest candidate below the bucket
-      const unsigned long long dmask = pass == 0 ? 0ull : ~0ull << (64 - 8 * pass);
+      const unsigned long long dmask = db == 0 ? 0ull : ~0ull << (64 - db);
       const int lane = threadIdx.x & 63;
       unsigned long long mx = 0ull;
       for (long long i0 = 0; i0 < (long long)n; i0 += 8ll * blockDim.x) {  // uniform trip count: wave-wide votes
@@ -688,7 +705,13 @@ __global__ void __launch_bounds__(1024) pdw_bracket_finish_kernel(long long F, c
       if (mx) atomicMax(&lt_max, mx);
       __syncthreads();
       const long long r_in = r;  // rank inside the bucket
-      k1 = block_select_key([&](long long i) { return members[i]; }, (long long)bucket, r, hist, pick, pass, pfx);
+      bool first = true;
+      while (db < 64) {  // the remaining bits, decided among the members
+        const int width = 64 - db < 8 ? 64 - db : 8;
+        block_digit_pass([&](long long i) { return members[i]; }, (long long)bucket, r, hist, pick, db, width, pfx, first);
+        first = false;
+      }
+      k1 = pfx;
       if (even && r0 > 0) {
         unsigned long long c = 0ull, m2 = 0ull;
         for (unsigned i = threadIdx.x; i < bucket; i += blockDim.x) {
@@ -985,6 +1008,7 @@ __global__ void pdw_rebase_kernel(int M, long long ntiles, unsigned long long* o
 
 struct ChanSrc {  // F x M channelizer output, frame-major complex64
   static constexpr int kCache = kPulseCache;
+  static constexpr int kThreads = 64;  // pulses are tens of frames and a pulse's workgroup is a chain of memory round trips: many small workgroups per CU
   const float2* y;
   int M;
   __device__ __forceinline__ double mag(long long i, int col) const { return mag_of(y[i * M + col]); }
@@ -1000,6 +1024,7 @@ struct ChanSrc {  // F x M channelizer output, frame-major complex64
 template <int FMT>
 struct RawSrc {
   static constexpr int kCache = kPulseCacheRaw;
+  static constexpr int kThreads = 256;
   const void* p;
   double inv_scale;  // 2^-(bit_width-1); 1 for cf32
   __device__ __forceinline__ void reim(long long i, double& re, double& im) const {
@@ -1071,8 +1096,8 @@ struct RawSrc {
 // ---------------------------------------------------------------------------------
 // per pulse
 
-template <class Src, int CACHE>
-__global__ void __launch_bounds__(256) pdw_pulse_kernel(Src src, int M, const long long* starts, const long long* ends,
+template <class Src, int CACHE, int THREADS>
+__global__ void __launch_bounds__(THREADS) pdw_pulse_kernel(Src src, int M, const long long* starts, const long long* ends,
                                                         const unsigned long long* base_s, const unsigned long long* base_e,
                                                         const double* nf, const double* bin_freqs, double fs, double fc,
                                                         double t0, unsigned flags, pfb_pdw* out, unsigned long long capacity) {
@@ -1083,14 +1108,20 @@ __global__ void __launch_bounds__(256) pdw_pulse_kernel(Src src, int M, const lo
   __shared__ int sat_flag;
   const unsigned long long pid = blockIdx.x;
   if (pid >= capacity) return;
-  // channel of this pulse: base_e is the exclusive prefix of tot_e over channels
-  int lo = 0, hi = M - 1;
-  while (lo < hi) {
-    const int mid_c = (lo + hi + 1) >> 1;
-    if (base_e[mid_c] <= pid) lo = mid_c; else hi = mid_c - 1;
+  // channel of this pulse: base_e is the exclusive prefix of tot_e over channels, so the pulse's channel is the largest
+  // one whose base <= pid (every later base is > pid).  Wave 0 counts those bases 64 at a time -- one memory round trip
+  // for M <= 64 lanes' worth, where a binary search would chain log2(M) of them.
+  __shared__ int chan;
+  if (threadIdx.x < 64) {
+    int cnt_le = 0;
+    for (int c0 = 0; c0 < M; c0 += 64) {
+      const int c = c0 + (int)threadIdx.x;
+      cnt_le += __popcll(__ballot(c < M && base_e[c] <= pid));
+    }
+    if (threadIdx.x == 0) chan = cnt_le - 1;  // base_e[0] = 0 <= pid
   }
-  // (the largest channel whose base <= pid is the pulse's channel: every later base is > pid)
-  const int b = lo;
+  __syncthreads();
+  const int b = chan;
   const unsigned long long k = pid - base_e[b];
   const long long toa = starts[base_s[b] + k], jj = ends[base_e[b] + k];
   const long long n = jj - toa + 1;
@@ -1125,13 +1156,13 @@ __global__ void __launch_bounds__(256) pdw_pulse_kernel(Src src, int M, const lo
   };
   double med;
   if (n <= CACHE) {  // one atan2 per sample: phases into the cache, steps into registers, steps back into the cache
-    constexpr int PER = (CACHE + 255) / 256;
+    constexpr int PER = (CACHE + THREADS - 1) / THREADS;
     for (long long i = threadIdx.x; i < n; i += blockDim.x) cache[i] = src.phase(toa + i, pcol);
     __syncthreads();
     double step[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-      const long long i = threadIdx.x + (long long)j * 256;
+      const long long i = threadIdx.x + (long long)j * THREADS;
       if (i < n - 1) {
         double d = cache[i + 1] - cache[i];
         if (d < -180.0) d += 360.0;
@@ -1142,7 +1173,7 @@ __global__ void __launch_bounds__(256) pdw_pulse_kernel(Src src, int M, const lo
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-      const long long i = threadIdx.x + (long long)j * 256;
+      const long long i = threadIdx.x + (long long)j * THREADS;
       if (i < n - 1) cache[i] = step[j];
     }
     __syncthreads();
@@ -1431,7 +1462,7 @@ int edges_and_pulses(Src src, int Mi, long long ntiles, int tile_words, const Ed
                        (const unsigned long long*)e.f1, Mi, ntiles, tile_words, (const unsigned char*)e.state,
                        (const unsigned long long*)e.off_s, (const unsigned long long*)e.off_e, d_starts, d_ends);
     if (n_out > 0) {
-      hipLaunchKernelGGL((pdw_pulse_kernel<Src, Src::kCache>), dim3((unsigned)n_out), dim3(256), 0, st, src, Mi, (const long long*)d_starts,
+      hipLaunchKernelGGL((pdw_pulse_kernel<Src, Src::kCache, Src::kThreads>), dim3((unsigned)n_out), dim3(Src::kThreads), 0, st, src, Mi, (const long long*)d_starts,
                          (const long long*)d_ends, (const unsigned long long*)e.base, (const unsigned long long*)(e.base + M),
                          (const double*)e.nf, (const double*)e.binf, fs, fc, t0, flags, d_out, n_out);
       PDW_TRY(hipGetLastError());
