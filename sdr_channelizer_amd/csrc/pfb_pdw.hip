@@ -1321,6 +1321,23 @@ struct Arena {
 std::mutex g_ws_mutex;
 Arena g_ws[kMaxDevices][2];
 
+// small pinned host block per device: the words that cross the bus in the middle of an extraction (edge totals, flags,
+// medians down; column bases up) move by DMA instead of through the runtime's pageable-copy staging
+struct HostPin {
+  char* p = nullptr;
+  size_t cap = 0;
+};
+HostPin g_pin[kMaxDevices];
+hipError_t pin_reserve(HostPin& h, size_t bytes) {
+  if (bytes <= h.cap) return hipSuccess;
+  if (h.p) (void)hipHostFree(h.p);
+  h.p = nullptr;
+  h.cap = 0;
+  const hipError_t e = hipHostMalloc((void**)&h.p, bytes, hipHostMallocDefault);
+  if (e == hipSuccess) h.cap = bytes;
+  return e;
+}
+
 hipError_t arena_reserve(Arena& a, size_t bytes) {
   a.used = 0;
   if (bytes <= a.cap) return hipSuccess;
@@ -1359,6 +1376,11 @@ extern "C" int pfb_pdw_release_workspace(int32_t device_id) {
       (void)hipSetDevice(d);
       (void)hipFree(a.p);
       a = Arena{};
+    }
+    if (g_pin[d].p) {
+      (void)hipSetDevice(d);
+      (void)hipHostFree(g_pin[d].p);
+      g_pin[d] = HostPin{};
     }
   }
   if (prev >= 0) (void)hipSetDevice(prev);
@@ -1423,9 +1445,20 @@ int edges_and_pulses(Src src, int Mi, long long ntiles, int tile_words, const Ed
   int rc = PFB_OK;
   const uint32_t M = (uint32_t)Mi;
   const size_t tm = (size_t)ntiles * M;
-  std::vector<unsigned long long> h_tot(2 * (size_t)M), h_base(2 * (size_t)M);
+  // pinned: [tot 2M u64 | base 2M u64 | nf M f64 | flags u32]
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  HostPin& pin = g_pin[dev];
+  unsigned long long *h_tot = nullptr, *h_base = nullptr;
+  double* p_nf = nullptr;
+  unsigned* p_check = nullptr;
   unsigned long long total_s = 0, total_e = 0;
   const unsigned tblocks = (unsigned)((tm + 255) / 256);
+  PDW_TRY(pin_reserve(pin, (5 * (size_t)M + 1) * sizeof(unsigned long long)));
+  h_tot = reinterpret_cast<unsigned long long*>(pin.p);
+  h_base = h_tot + 2 * (size_t)M;
+  p_nf = reinterpret_cast<double*>(h_base + 2 * (size_t)M);
+  p_check = reinterpret_cast<unsigned*>(p_nf + M);
   hipLaunchKernelGGL(pdw_tilefn_kernel, dim3(tblocks), dim3(256), 0, st, (const unsigned long long*)e.f0,
                      (const unsigned long long*)e.f1, Mi, ntiles, tile_words, e.fn, e.cnt);
   if (Mi >= 32 && ntiles < 2048) {
@@ -1436,13 +1469,17 @@ int edges_and_pulses(Src src, int Mi, long long ntiles, int tile_words, const Ed
                        (const ushort4*)e.cnt, e.state, e.off_s, e.off_e, e.tot, e.tot + M);
   }
   PDW_TRY(hipGetLastError());
-  PDW_TRY(hipMemcpyAsync(h_tot.data(), e.tot, 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  PDW_TRY(hipMemcpyAsync(h_tot, e.tot, 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   if (d_check) {
-    PDW_TRY(hipMemcpyAsync(h_check, d_check, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    PDW_TRY(hipMemcpyAsync(h_nf, e.nf, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
+    PDW_TRY(hipMemcpyAsync(p_check, d_check, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    PDW_TRY(hipMemcpyAsync(p_nf, e.nf, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   PDW_TRY(hipStreamSynchronize(st));
-  if (d_check && (*h_check & 3u)) return kRedo;
+  if (d_check) {
+    *h_check = *p_check;
+    std::memcpy(h_nf, p_nf, (size_t)M * sizeof(double));
+    if (*h_check & 3u) return kRedo;
+  }
   for (uint32_t b = 0; b < M; ++b) {  // channels outermost, like the reference's for bin = 1:M
     h_base[b] = total_s; h_base[M + b] = total_e;
     total_s += h_tot[b]; total_e += h_tot[M + b];
@@ -1455,7 +1492,7 @@ int edges_and_pulses(Src src, int Mi, long long ntiles, int tile_words, const Ed
     long long* d_starts = take<long long>(ws2, (size_t)total_s);
     long long* d_ends = take<long long>(ws2, (size_t)total_e);
     pfb_pdw* d_out = take<pfb_pdw>(ws2, (size_t)n_out);
-    PDW_TRY(hipMemcpyAsync(e.base, h_base.data(), 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    PDW_TRY(hipMemcpyAsync(e.base, h_base, 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(pdw_rebase_kernel, dim3(tblocks), dim3(256), 0, st, Mi, ntiles, e.off_s, e.off_e,
                        (const unsigned long long*)e.base, (const unsigned long long*)(e.base + M));
     hipLaunchKernelGGL(pdw_edges_kernel, dim3(tblocks), dim3(256), 0, st, (const unsigned long long*)e.f0,

@@ -21,7 +21,8 @@ _tls = threading.local()
 
 def _out_buffer(capacity: int):
     """The landing zone of a call's PDWs: one buffer per thread, kept (and its pages touched) between calls -- a fresh
-    48 MB np.zeros per call costs more than the extraction's host side; callers get a copy of the records found."""
+    48 MB np.zeros per call costs more than the extraction's host side; callers get a copy of the records found.
+    (Page-locking it was tried: 0.05 ms per call for a 140 ms first call -- not kept.)"""
     buf = getattr(_tls, "out", None)
     if buf is None or len(buf) < capacity:
         buf = _tls.out = np.empty(max(int(capacity), 1), dtype=PDW_DTYPE)
