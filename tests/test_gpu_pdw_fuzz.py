@@ -84,3 +84,44 @@ def test_raw_pdws_random(oracle, case):
         return xs[a:a + int(round(p["pw"] * fs)) + 1]
 
     compare(got, want, fs, phase_col=phase_col)
+
+
+LONG_CASES = max(6, CASES // 5)
+
+
+@pytest.mark.parametrize("case", range(LONG_CASES))
+def test_channelized_pdws_random_long_streams(oracle, case):
+    """F >= 8 * 65536 frames: the sampled-bracket route (float32 screen, parked candidates, bracket finish) on random
+    shapes, amplitude scales from 1e-18 to 1e15 (the screen hands very small and very large magnitudes to the exact
+    route), coarse grids (ties), non-stationary noise and low thresholds (many samples near the threshold).  Medians exact,
+    PDWs the oracle's; whichever route the data force (1 / 4 sampled, 3 full select after a failed proof)."""
+    from sdr_channelizer_amd import _lib as L
+    rng = np.random.default_rng(11000 + case)
+    F = int(rng.integers(8 * 65536, 8 * 65536 + 300000))
+    M = int(rng.integers(1, 12))
+    scale = float(10.0 ** rng.choice([-18.0, -6.0, -2.0, -2.0, -2.0, 0.0, 3.0, 15.0]))
+    y = rng.standard_normal((F, M), dtype=np.float32) + 1j * rng.standard_normal((F, M), dtype=np.float32)
+    if rng.random() < 0.4:  # the noise level drifts along the record
+        y *= np.linspace(1.0, float(rng.uniform(1.0, 3.0)), F, dtype=np.float32)[:, None]
+    if rng.random() < 0.3:  # moderately tied magnitudes
+        g = float(rng.choice([50.0, 400.0, 3000.0]))
+        y = np.round(y.real * g) / g + 1j * np.round(y.imag * g) / g
+    y = (y * np.float32(0.01)).astype(np.complex64)
+    for b in rng.integers(0, M, size=int(rng.integers(1, 4))):
+        for _ in range(int(rng.integers(1, 5))):
+            a, n = int(rng.integers(0, F - 5000)), int(rng.integers(1, 4000))
+            y[a:a + n, b] += (rng.uniform(0.2, 1.0) * np.exp(1j * np.deg2rad(rng.uniform(-170, 170)) * np.arange(n))).astype(np.complex64)
+    y = (y.astype(np.complex128) * scale).astype(np.complex64)
+    snr = float(rng.choice([3.0, 6.0, 10.0, 15.0]))
+    got, nf = extract_pdws(y, 8e6, 1e9, 0.0, snr_threshold_db=snr, return_noise_floor=True)
+    assert L.load().pfb_pdw_last_noise_floor_path() in (1, 3, 4)
+    yd = y.astype(np.complex128)
+    assert np.allclose(nf, np.median(np.abs(yd), axis=0), rtol=1e-12, atol=0)
+    want = oracle.extract_pdws(yd, 8e6, 1e9, 0.0, snr, max_out=1 << 20)
+
+    def phase_col(i):  # the samples pulse i spans (t0 = 0 here); the scripts' quirk reads the phases of column 1
+        a = int(round(want[i]["toa"] * 8e6 / M)) - 1
+        return y[a:a + int(round(want[i]["pw"] * 8e6 / M)) + 1, 0]
+
+    compare(got, want, 8e6 / M, phase_col=phase_col)
+    L.load().pfb_pdw_release_workspace(-1)
