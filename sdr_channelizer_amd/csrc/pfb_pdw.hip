@@ -1264,31 +1264,79 @@ __global__ void __launch_bounds__(256) pdw_raw_below_kernel(Src src, long long n
   if (any) { atomicAdd(below, nb); atomicMax(max_below, best); }
 }
 
+// OR of x over the 16 lanes of a DPP row, left in every lane of the row (row_ror 1, 2, 4, 8)
+__device__ __forceinline__ unsigned row_or(unsigned x) {
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false);
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false);
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false);
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false);
+  return x;
+}
+
 // comparison masks of the raw stream.  A wave covers 64 consecutive words: in step i every lane compares
-// sample 64 * (w0 + i) + lane (one coalesced load), the wave votes, lane i keeps the word.
-template <class Src>
-__global__ void __launch_bounds__(256) pdw_raw_mask_kernel(Src src, long long n, double lead, double trail,
+// sample 64 * (w0 + i) + lane (one coalesced load), the wave votes, lane i keeps the word.  The magnitude is a
+// monotone function of the sample's |x|^2 key (sqrt, then an exact power-of-two scale), so `mag >= lead` and
+// `mag > trail` are comparisons of the KEY with the first key whose magnitude passes -- found by the host with the
+// same float64 operations -- and the pass does no float64 arithmetic at all.  key_max: the largest key that is a
+// number (an infinity passes every threshold, a NaN none, as with the magnitudes themselves).
+template <class Src, bool VEC>
+__global__ void __launch_bounds__(256) pdw_raw_mask_kernel(Src src, long long n, unsigned long long key_ge,
+                                                           unsigned long long key_gt, unsigned long long key_max,
                                                            unsigned long long* f0, unsigned long long* f1, long long words) {
   const int lane = threadIdx.x & 63;
   const long long w0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
   if (w0 >= words) return;
   unsigned long long a = 0ull, b = 0ull;
-  for (int i0 = 0; i0 < 64; i0 += 16) {  // sixteen loads in flight per lane
-    bool ge[16], gt[16];
+  if (VEC && (w0 + 64) * 64 <= n) {
+    // wide loads: in step u the wave reads 256 consecutive samples, four per lane (one 16-byte load for int16); a lane's
+    // four comparison bits go to their place in the word its 16-lane row is building, the row ORs itself together
+    // (DPP rotations), and lanes 4u .. 4u+3 keep the four finished words
+#pragma unroll 1
+    for (int u0 = 0; u0 < 16; u0 += 8) {  // eight loads in flight per lane
+      unsigned long long k[8][4];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const long long sidx = (w0 + i0 + u) * 64 + lane;
-      ge[u] = false; gt[u] = true;  // past the end: identity
-      if (sidx < n) {
-        const double m = src.mag(sidx, 0);
-        ge[u] = m >= lead;
-        gt[u] = m > trail;
+      for (int u = 0; u < 8; ++u) src.key4(((w0 * 64) >> 2) + (long long)(u0 + u) * 64 + lane, k[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        unsigned na = 0u, nb = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          na |= (unsigned)(k[u][j] >= key_ge && k[u][j] <= key_max) << j;
+          nb |= (unsigned)(k[u][j] >= key_gt && k[u][j] <= key_max) << j;
+        }
+        // lanes 0-7 of a row fill the word's low half, lanes 8-15 the high half; OR over the row by DPP rotations
+        const int sh = 4 * (lane & 7);
+        const bool upper = (lane & 8) != 0;
+        const unsigned a_lo = row_or(upper ? 0u : na << sh), a_hi = row_or(upper ? na << sh : 0u);
+        const unsigned b_lo = row_or(upper ? 0u : nb << sh), b_hi = row_or(upper ? nb << sh : 0u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // row j holds word 4 (u0 + u) + j
+          const unsigned long long wa = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)a_hi, 16 * j) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)a_lo, 16 * j);
+          const unsigned long long wb = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)b_hi, 16 * j) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)b_lo, 16 * j);
+          if (lane == 4 * (u0 + u) + j) { a = wa; b = wb; }
+        }
       }
     }
+  } else {
+    for (int i0 = 0; i0 < 64; i0 += 16) {  // sixteen loads in flight per lane
+      bool ge[16], gt[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const unsigned long long wa = __ballot(ge[u]), wb = __ballot(gt[u]);
-      if (lane == i0 + u) { a = wa; b = wb; }
+      for (int u = 0; u < 16; ++u) {
+        const long long sidx = (w0 + i0 + u) * 64 + lane;
+        ge[u] = false; gt[u] = true;  // past the end: identity
+        if (sidx < n) {
+          const unsigned long long k = src.key(sidx);
+          ge[u] = k >= key_ge && k <= key_max;
+          gt[u] = k >= key_gt && k <= key_max;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const unsigned long long wa = __ballot(ge[u]), wb = __ballot(gt[u]);
+        if (lane == i0 + u) { a = wa; b = wb; }
+      }
     }
   }
   if (w0 + lane < words) { f0[w0 + lane] = a; f1[w0 + lane] = b; }
@@ -1785,20 +1833,32 @@ int extract_raw(const void* d_iq, long long n, double inv_scale, double fs, doub
       return (FMT == PFB_FMT_CF32) ? std::sqrt(dkey_inv_host(k)) : std::sqrt((double)k) * inv_scale;
     };
     unsigned long long v0 = prefix;
-    if ((n & 1) == 0) {  // even count: the lower middle value is the largest key below, unless the pivot repeats
-      PDW_TRY(hipMemsetAsync(d_pair, 0, 2 * sizeof(unsigned long long), st));
-      if (vec) {
-        hipLaunchKernelGGL((pdw_raw_below_kernel<RawSrc<FMT>, true>), dim3(grid), dim3(256), 0, st, src, n, prefix, d_pair,
-                           d_pair + 1);
+    if ((n & 1) == 0 && rank == 0) {
+      // even count and the pivot is the first of its value in the order: the lower middle value is the largest key below
+      // it.  All of the pivot's bits are decided, so the last pass's histogram (h_hist: the lowest digit among the keys
+      // that share every higher bit) usually names it -- the nearest occupied digit below the pivot's; only when that
+      // bucket holds nothing smaller does the data have to be read once more.
+      const int dl = (int)((prefix >> pass[npass - 1].shift) & ((1u << pass[npass - 1].bits) - 1u));
+      int dn = dl - 1;
+      while (dn >= 0 && h_hist[dn] == 0u) --dn;
+      if (dn >= 0) {
+        v0 = (prefix & ~((unsigned long long)((1u << pass[npass - 1].bits) - 1u) << pass[npass - 1].shift)) |
+             ((unsigned long long)dn << pass[npass - 1].shift);
       } else {
-        hipLaunchKernelGGL((pdw_raw_below_kernel<RawSrc<FMT>, false>), dim3(grid), dim3(256), 0, st, src, n, prefix, d_pair,
-                           d_pair + 1);
+        PDW_TRY(hipMemsetAsync(d_pair, 0, 2 * sizeof(unsigned long long), st));
+        if (vec) {
+          hipLaunchKernelGGL((pdw_raw_below_kernel<RawSrc<FMT>, true>), dim3(grid), dim3(256), 0, st, src, n, prefix, d_pair,
+                             d_pair + 1);
+        } else {
+          hipLaunchKernelGGL((pdw_raw_below_kernel<RawSrc<FMT>, false>), dim3(grid), dim3(256), 0, st, src, n, prefix, d_pair,
+                             d_pair + 1);
+        }
+        PDW_TRY(hipGetLastError());
+        PDW_TRY(hipMemcpyAsync(h_pair, d_pair, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        PDW_TRY(hipStreamSynchronize(st));
+        if (h_pair[0] == (unsigned long long)(n / 2)) v0 = h_pair[1];
       }
-      PDW_TRY(hipGetLastError());
-      PDW_TRY(hipMemcpyAsync(h_pair, d_pair, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-      PDW_TRY(hipStreamSynchronize(st));
-      if (h_pair[0] == (unsigned long long)(n / 2)) v0 = h_pair[1];
-    }
+    }  // (rank > 0: the pivot's value repeats below the middle, v0 = the pivot)
     nf = (n & 1) ? key_mag(prefix) : 0.5 * (key_mag(v0) + key_mag(prefix));
     lead = nf * std::pow(10.0, lead_db / 10.0);    // :45-46
     trail = nf * std::pow(10.0, trail_db / 10.0);  // :47
@@ -1806,9 +1866,32 @@ int extract_raw(const void* d_iq, long long n, double inv_scale, double fs, doub
   }
   PDW_TRY(hipMemcpyAsync(e.nf, &nf, sizeof(double), hipMemcpyHostToDevice, st));
   PDW_TRY(hipStreamSynchronize(st));  // nf lives on this stack frame
-  // ---- edges (:54-105) and pulses
-  hipLaunchKernelGGL(pdw_raw_mask_kernel<RawSrc<FMT>>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, src, n, lead,
-                     trail, e.f0, e.f1, words);
+  // ---- edges (:54-105) and pulses.  The thresholds as keys: the first key whose magnitude is >= lead / > trail
+  {
+    auto key_mag = [&](unsigned long long k) {
+      return (FMT == PFB_FMT_CF32) ? std::sqrt(dkey_inv_host(k)) : std::sqrt((double)k) * inv_scale;
+    };
+    const unsigned long long k_lo = (FMT == PFB_FMT_CF32) ? 0x8000000000000000ull : 0ull;               // |x|^2 = 0
+    const unsigned long long k_hi = (FMT == PFB_FMT_CF32) ? 0xFFF0000000000000ull : (1ull << 33);       // +inf / above any sample
+    auto first_key = [&](auto pred) {  // smallest key in [k_lo, k_hi] that passes, k_hi + 1 if none (pred is monotone)
+      if (!pred(k_hi)) return k_hi + 1;
+      unsigned long long lo = k_lo, hi = k_hi;  // invariant: pred(hi)
+      while (lo < hi) {
+        const unsigned long long mid = lo + (hi - lo) / 2;
+        if (pred(mid)) hi = mid; else lo = mid + 1;
+      }
+      return lo;
+    };
+    const unsigned long long key_ge = first_key([&](unsigned long long k) { return key_mag(k) >= lead; });
+    const unsigned long long key_gt = first_key([&](unsigned long long k) { return key_mag(k) > trail; });
+    if (vec) {
+      hipLaunchKernelGGL((pdw_raw_mask_kernel<RawSrc<FMT>, true>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, src, n,
+                         key_ge, key_gt, k_hi, e.f0, e.f1, words);
+    } else {
+      hipLaunchKernelGGL((pdw_raw_mask_kernel<RawSrc<FMT>, false>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, src, n,
+                         key_ge, key_gt, k_hi, e.f0, e.f1, words);
+    }
+  }
   PDW_TRY(hipGetLastError());
   rc = edges_and_pulses(src, 1, ntiles, tile_words, e, ws2, fs, fc, t0, 0u, out, capacity, count, st);
 done:
