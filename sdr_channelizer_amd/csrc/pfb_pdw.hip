@@ -135,47 +135,98 @@ __device__ void block_digit_pass(GetKey getkey, long long n, long long& k, unsig
   __syncthreads();
 }
 
-// k-th smallest of n 64-bit keys produced by getkey(i), by passes of 8-bit digits first_pass .. end_pass-1 (most
-// significant digit = pass 0).  Returns the key's digits decided so far (lower bits zero); k becomes the rank inside
-// the last bucket, whose size is still in hist[last digit] on return.
-template <int INFLIGHT = 4, class GetKey>
-__device__ unsigned long long block_select_key(GetKey getkey, long long n, long long& k, unsigned* hist /* [256] shared */,
-                                               unsigned long long* pick /* [2] shared */, int first_pass = 0,
-                                               unsigned long long prefix = 0ull /* the first_pass digits decided so far */,
-                                               int end_pass = 8, bool all_share = true /* every value has those digits */) {
-  int db = 8 * first_pass;
-  for (int pass = first_pass; pass < end_pass; ++pass)
-    block_digit_pass<INFLIGHT>(getkey, n, k, hist, pick, db, 8, prefix, pass == first_pass && all_share);
-  return prefix;
-}
-
-// k-th smallest of n doubles produced by get(i): all eight digits of the order-preserving key
+// MATLAB median of n doubles produced by get(i) (any order; called by the whole workgroup with the same n).
+// One scan finds the smallest and the largest key, whose common leading bits every key shares; the 8 bits right below
+// spread the values over up to 256 buckets, so ONE digit pass usually leaves the middle value's bucket with a few dozen
+// members (further passes only while it holds more than kCountingMedian); a third scan moves the bucket into
+// `scratch` and remembers the largest key below it; the two middle order statistics are then found among the members
+// by rank counting (every member counts the smaller ones).  Three scans instead of the nine of a full 8-digit select
+// plus its counting pass.
 template <class Get>
-__device__ double block_select(Get get, long long n, long long k, unsigned* hist /* [256] shared */,
-                               unsigned long long* pick /* [2] shared */, int first_pass = 0,
-                               unsigned long long prefix = 0ull) {
-  return dkey_inv(block_select_key([&](long long i) { return dkey(get(i)); }, n, k, hist, pick, first_pass, prefix));
-}
-
-// MATLAB median.  For an even count the lower middle value is the largest value below the upper one,
-// unless the upper one repeats (fewer than n/2 values lie below it): one counting pass, not a second select.
-template <class Get>
-__device__ double block_median(Get get, long long n, unsigned* hist, unsigned long long* pick) {
-  const double hi = block_select(get, n, n / 2, hist, pick);
-  if (n & 1) return hi;
-  if (threadIdx.x == 0) { pick[0] = 0ull; pick[1] = 0ull; }
+__device__ double block_median(Get get, long long n, unsigned* hist /* [256] shared */, unsigned long long* pick /* [2] shared */,
+                               unsigned long long* scratch /* [kCountingMedian] shared */) {
+  __shared__ unsigned long long s_min, s_max, s_ltmax, s_hi, s_lo;
+  __shared__ unsigned s_n;
+  if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_ltmax = 0ull; s_n = 0u; s_hi = 0ull; s_lo = 0ull; }
   __syncthreads();
-  const unsigned long long kh = dkey(hi);
-  unsigned long long c = 0ull, mx = 0ull;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-    const unsigned long long k = dkey(get(i));
-    if (k < kh) { ++c; mx = k > mx ? k : mx; }
+  auto getkey = [&](long long i) { return dkey(get(i)); };
+  {
+    unsigned long long mn = ~0ull, mx = 0ull;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+      const unsigned long long k = getkey(i);
+      mn = k < mn ? k : mn;
+      mx = k > mx ? k : mx;
+    }
+    atomicMin(&s_min, mn);
+    atomicMax(&s_max, mx);
   }
-  if (c) { atomicAdd(&pick[0], c); atomicMax(&pick[1], mx); }
   __syncthreads();
-  const double lo = (pick[0] == (unsigned long long)(n / 2)) ? dkey_inv(pick[1]) : hi;
-  __syncthreads();
-  return 0.5 * (lo + hi);
+  const unsigned long long kmin = s_min, kmax = s_max;
+  long long r = n / 2;  // rank of the upper middle value
+  int db = kmin == kmax ? 64 : __clzll((long long)(kmin ^ kmax));  // bits every key shares
+  unsigned long long pfx = db == 64 ? kmin : (db ? kmin & (~0ull << (64 - db)) : 0ull);
+  unsigned long long bucket = (unsigned long long)n;
+  bool first = true;
+  while (db < 64 && bucket > (unsigned long long)kCountingMedian) {  // uniform
+    const int width = 64 - db < 8 ? 64 - db : 8;
+    block_digit_pass(getkey, n, r, hist, pick, db, width, pfx, first);
+    first = false;
+    bucket = hist[(unsigned)(pfx >> (64 - db)) & ((1u << width) - 1u)];
+    __syncthreads();
+  }
+  unsigned long long khi, klo;
+  if (db == 64) {  // the bucket is one value (all keys equal, or heavy ties)
+    khi = pfx;
+    klo = pfx;
+    if (r == 0 && (n & 1) == 0) {  // the lower middle value is the largest key below
+      unsigned long long mx = 0ull;
+      for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned long long k = getkey(i);
+        if (k < pfx) mx = k > mx ? k : mx;
+      }
+      if (mx) atomicMax(&s_ltmax, mx);
+      __syncthreads();
+      klo = s_ltmax;
+    }
+  } else {
+    const unsigned long long dmask = db == 0 ? 0ull : ~0ull << (64 - db);
+    const int lane = threadIdx.x & 63;
+    unsigned long long mx = 0ull;
+    for (long long i0 = 0; i0 < n; i0 += blockDim.x) {  // uniform trip count: wave-wide votes
+      const long long i = i0 + threadIdx.x;
+      const unsigned long long k = i < n ? getkey(i) : 0ull;
+      const bool in = i < n && (k & dmask) == pfx;
+      if (i < n && k < pfx) mx = k > mx ? k : mx;
+      const unsigned long long vote = __ballot(in);
+      if (vote) {
+        const int leader = __ffsll((long long)vote) - 1;
+        unsigned base = 0u;
+        if (lane == leader) base = atomicAdd(&s_n, (unsigned)__popcll(vote));
+        base = (unsigned)__shfl((int)base, leader);
+        if (in) scratch[base + (unsigned)__popcll(vote & ((1ull << lane) - 1ull))] = k;
+      }
+    }
+    if (mx) atomicMax(&s_ltmax, mx);
+    __syncthreads();
+    const int m = (int)bucket;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+      const unsigned long long ki = scratch[i];
+      long long rank = 0;
+      for (int j = 0; j < m; ++j) {
+        const unsigned long long kj = scratch[j];
+        rank += (kj < ki) || (kj == ki && j < i);
+      }
+      if (rank == r) s_hi = ki;
+      if (rank == r - 1) s_lo = ki;
+    }
+    __syncthreads();
+    khi = s_hi;
+    klo = r > 0 ? s_lo : s_ltmax;
+  }
+  const double hi = dkey_inv(khi);
+  const double res = (n & 1) ? hi : 0.5 * (dkey_inv(klo) + hi);
+  __syncthreads();  // the shared words are free for the next call
+  return res;
 }
 
 // median of the n <= kCountingMedian values in v[] (LDS) by rank counting: element i has rank
@@ -1106,6 +1157,11 @@ __global__ void __launch_bounds__(THREADS) pdw_pulse_kernel(Src src, int M, cons
   __shared__ double cache[CACHE];
   __shared__ double mid[2];
   __shared__ int sat_flag;
+  // the bucket of block_median: its own array when cached pulses can be longer than the counting median handles,
+  // otherwise the cache itself (block_median then only runs for pulses too long to be cached)
+  __shared__ unsigned long long bucket_store[CACHE > kCountingMedian ? kCountingMedian : 1];
+  static_assert(CACHE >= kCountingMedian, "the cache doubles as the bucket");
+  unsigned long long* scratch = CACHE > kCountingMedian ? bucket_store : reinterpret_cast<unsigned long long*>(cache);
   const unsigned long long pid = blockIdx.x;
   if (pid >= capacity) return;
   // channel of this pulse: base_e is the exclusive prefix of tot_e over channels, so the pulse's channel is the largest
@@ -1141,9 +1197,9 @@ __global__ void __launch_bounds__(THREADS) pdw_pulse_kernel(Src src, int M, cons
     for (long long i = threadIdx.x; i < n; i += blockDim.x) cache[i] = src.mag(toa + i, b);
     __syncthreads();
     amp = (n <= kCountingMedian) ? cached_median(cache, (int)n, mid)
-                                 : block_median([&](long long i) { return cache[i]; }, n, hist, pick);
+                                 : block_median([&](long long i) { return cache[i]; }, n, hist, pick, scratch);
   } else {
-    amp = block_median([&](long long i) { return src.mag(toa + i, b); }, n, hist, pick);
+    amp = block_median([&](long long i) { return src.mag(toa + i, b); }, n, hist, pick, scratch);
   }
   __syncthreads();
 
@@ -1178,9 +1234,9 @@ __global__ void __launch_bounds__(THREADS) pdw_pulse_kernel(Src src, int M, cons
     }
     __syncthreads();
     med = (n - 1 <= kCountingMedian) ? cached_median(cache, (int)(n - 1), mid)
-                                     : block_median([&](long long i) { return cache[i]; }, n - 1, hist, pick);
+                                     : block_median([&](long long i) { return cache[i]; }, n - 1, hist, pick, scratch);
   } else {
-    med = block_median(dphi, n - 1, hist, pick);
+    med = block_median(dphi, n - 1, hist, pick, scratch);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
