@@ -343,3 +343,44 @@ def test_raw_stream_argument_checks_and_silence(oracle):
     want, _ = oracle.extract_pdws_raw(np.zeros(1000, np.complex128), 1e6, 0.0, 0.0)
     assert len(want) == 500
     compare(got, want, 1e6)
+
+
+def test_extraction_past_2_31_matrix_elements():
+    """64-bit indexing through the whole PDW pipeline: a 2^27 x 20 matrix (2.7e9 elements, 21 GB) built as 128 copies of
+    a 2^20 x 20 one.  The multiset of magnitudes is the small one's with every value 128 times, so the medians are
+    identical, and with quiet margins at both ends of the small matrix the pulses of the big one are the small one's,
+    128 times, shifted by whole copies."""
+    import torch
+    Fs, M, reps = 1 << 20, 20, 128
+    need = reps * Fs * M * 8
+    if torch.cuda.mem_get_info()[0] < need * 1.5:
+        pytest.skip(f"needs {need >> 30} GiB of HBM")
+    rng = np.random.default_rng(5)
+    y = (0.01 * (rng.standard_normal((Fs, M), dtype=np.float32) + 1j * rng.standard_normal((Fs, M), dtype=np.float32))).astype(np.complex64)
+    for _ in range(40):
+        b, a, n = int(rng.integers(0, M)), int(rng.integers(1000, Fs - 6000)), int(rng.integers(1, 3000))
+        y[a:a + n, b] += (rng.uniform(0.3, 0.9) * np.exp(1j * np.deg2rad(rng.uniform(-170, 170)) * np.arange(n))).astype(np.complex64)
+    fs_in, fc = 20e6, 1e9
+    small, nf_small = extract_pdws(y, fs_in, fc, 0.0, return_noise_floor=True)
+    assert len(small) >= 20
+    yd = torch.from_numpy(y).cuda()
+    big_y = yd.repeat(reps, 1)
+    del yd
+    big, nf_big = extract_pdws(big_y, fs_in, fc, 0.0, return_noise_floor=True, capacity=1 << 18)
+    del big_y
+    torch.cuda.empty_cache()
+    assert np.array_equal(nf_big, nf_small)
+    assert len(big) == reps * len(small)
+    # the reference's order: channels outermost, time within a channel
+    order = np.lexsort((big["toa"], big["bin"]))
+    assert np.array_equal(order, np.arange(len(big)))
+    fs = fs_in / M
+    for c in np.unique(small["bin"]):
+        s, bg = small[small["bin"] == c], big[big["bin"] == c]
+        want_toa = (s["toa"][None, :] + (np.arange(reps) * Fs / fs)[:, None]).ravel()
+        assert np.allclose(bg["toa"], want_toa, rtol=0, atol=1e-9)
+        for f in ("pw", "snr", "mag", "freq"):
+            assert np.array_equal(bg[f], np.tile(s[f], reps)), f
+        assert np.array_equal(bg["sat"], np.tile(s["sat"], reps))
+    from sdr_channelizer_amd import _lib as L
+    L.load().pfb_pdw_release_workspace(-1)
