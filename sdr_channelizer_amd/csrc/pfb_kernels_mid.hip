@@ -42,6 +42,13 @@ using Cfg10x12i16 = FastCfg<10, 12, 10, 1, PFB_FMT_INT16_IQ, 8, 2, 5, 2, 1, 2, 5
 using Cfg20x12i16 = FastCfg<20, 12, 20, 1, PFB_FMT_INT16_IQ, 8, 2, 10, 2, 1, 2, 15, 0, 42, true, 3>;
 using Cfg40x12i16 = FastCfg<40, 12, 40, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 5, 1, 5, 9, 0, 45, true, 4>;
 
+// complex float32 input (what a MATLAB caller holds after normalising, channelizer_example.m:44-56) for the reference's
+// own band count, cfg5's and cfg3's shapes: the same plans with 8-byte samples (no spills; M = 64 and M = 8 have theirs
+// next to the integer ones).  Everything else in cf32 takes the generic kernel.
+using Cfg56x12f32 = FastCfg<56, 12, 56, 1, PFB_FMT_CF32, 8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
+using Cfg128x12os2f32 = FastCfg<128, 12, 64, 1, PFB_FMT_CF32, 8, 2, 16, 8, 1, 8, 17, 0, 136, false, 2>;
+using Cfg256x8f32 = FastCfg<256, 8, 256, 4, PFB_FMT_CF32, 4, 2, 16, 16, 1, 17, 17, 0, 272, false, 2>;
+
 // M = 32 with 8-bit samples: in the ordinary kernel half the lanes of every 2-byte row load are idle, and sub-dword
 // loads cost the memory pipeline as much as full ones -- 25 % of roofline.  Two segments per wave (SegKernel) fill
 // the loads: 47 % (with 4-byte samples the ordinary kernel stays ahead, 54 vs 51 %)
@@ -66,6 +73,9 @@ static const FastEntry kRows[] = {
     seg_entry<Cfg40x12i16>("pfb_fast<M40,P12,D40,int16>", 1024),
     entry<Cfg56x12i16>("pfb_fast<M56,P12,D56,int16>", 512, 7),
     entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 7),
+    entry<Cfg56x12f32>("pfb_fast<M56,P12,D56,cf32>", 512, 7),
+    entry<Cfg128x12os2f32>("pfb_fast<M128,P12,D64,cf32>", 64, 0),
+    entry<Cfg256x8f32>("pfb_fast<M256,P8,D256,cf32>", 32, 11),
 };
 
 FastTablePart fast_table_mid() { return FastTablePart{kRows, (int)(sizeof(kRows) / sizeof(kRows[0]))}; }
