@@ -36,6 +36,12 @@ using Cfg560x12i16t =
 using Cfg560x12i8t =
     FastCfg<560, 12, 560, 2, PFB_FMT_INT8_IQ, 4, 3, 14, 10, 4, 40, 60, 140, 600, false, 3, false>;
 
+// complex float32 input at the training script's band count (generate_channelized_training_iq.m:95-100 channelizes data
+// that only exists as complex doubles in MATLAB's memory) and at cfg4's: the lockstep plans, whose one column per thread
+// leaves room for 8-byte samples (the team plans' two-column FIR window spills 40-100 registers with them)
+using Cfg560x12f32 = FastCfg<560, 12, 560, 1, PFB_FMT_CF32, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;
+using Cfg1024x16f32b = FastCfg<1024, 16, 1024, 1, PFB_FMT_CF32, 8, 3, 8, 8, 16, 128, 128, 65, 1040, false, 1, true>;
+
 static const FastEntry kRows[] = {
     entry<Cfg1024x16i16t>("pfb_fast<M1024,P16,D1024,int16>", 512, 6),
     entry<Cfg1024x16i16b>("pfb_fast<M1024,P16,D1024,int16,16w>", 256, 0),
@@ -46,6 +52,8 @@ static const FastEntry kRows[] = {
     entry<Cfg560x12i8>("pfb_fast<M560,P12,D560,int8>", 252, 0),
     entry<Cfg560x12i16>("pfb_fast<M560,P12,D560,int16,9w>", 252, 0),
     entry<Cfg560x12i8t>("pfb_fast<M560,P12,D560,int8,teams>", 512, 6),
+    entry<Cfg560x12f32>("pfb_fast<M560,P12,D560,cf32>", 252, 0),
+    entry<Cfg1024x16f32b>("pfb_fast<M1024,P16,D1024,cf32>", 256, 0),
 };
 
 FastTablePart fast_table_big() { return FastTablePart{kRows, (int)(sizeof(kRows) / sizeof(kRows[0]))}; }

@@ -44,7 +44,7 @@ using Cfg40x12i16 = FastCfg<40, 12, 40, 1, PFB_FMT_INT16_IQ, 8, 2, 8, 5, 1, 5, 9
 
 // complex float32 input (what a MATLAB caller holds after normalising, channelizer_example.m:44-56) for the reference's
 // own band count, cfg5's and cfg3's shapes: the same plans with 8-byte samples (no spills; M = 64 and M = 8 have theirs
-// next to the integer ones).  Everything else in cf32 takes the generic kernel.
+// next to the integer ones, M = 560 and 1024 in pfb_kernels_big.hip).  Everything else in cf32 takes the generic kernel.
 using Cfg56x12f32 = FastCfg<56, 12, 56, 1, PFB_FMT_CF32, 8, 2, 8, 7, 1, 7, 9, 0, 71, false, 4>;
 using Cfg128x12os2f32 = FastCfg<128, 12, 64, 1, PFB_FMT_CF32, 8, 2, 16, 8, 1, 8, 17, 0, 136, false, 2>;
 using Cfg256x8f32 = FastCfg<256, 8, 256, 4, PFB_FMT_CF32, 4, 2, 16, 16, 1, 17, 17, 0, 272, false, 2>;

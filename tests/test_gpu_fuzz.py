@@ -17,9 +17,9 @@ SHAPES = [
     (64, 16, 64, ("int16",), (0, 4, 7, 8)),
     (128, 12, 64, ("int16", "cf32"), (0, 2, 3, 7, 8)),
     (256, 8, 256, ("int8", "int16", "cf32"), (0, 2, 8)),
-    (1024, 16, 1024, ("int16",), (0, 6)),
+    (1024, 16, 1024, ("int16", "cf32"), (0, 6)),
     (56, 12, 56, ("int16", "int8", "cf32"), (0, 2, 3, 7, 8)),
-    (560, 12, 560, ("int16", "int8"), (0, 6)),
+    (560, 12, 560, ("int16", "int8", "cf32"), (0, 6)),
     (32, 12, 32, ("int16", "int8"), (0, 2, 7, 8)),
     (16, 12, 16, ("int16", "int8"), (0,)),
     (8, 12, 8, ("int16", "int8", "cf32"), (0,)),

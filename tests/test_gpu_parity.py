@@ -87,7 +87,8 @@ def test_one_hot_tap_bit_exact(M, P, D, fmt, bw, q0):
     (12, 5, 4, "int8", 8, 4 * 500), (560, 12, 560, "int16", 12, 560 * 150 + 31), (560, 12, 560, "int8", 8, 560 * 64),
     (56, 12, 56, "int8", 8, 56 * 1500 + 3), (16, 12, 16, "int16", 12, 16 * 4000 + 9), (8, 12, 8, "int16", 12, 8 * 9000 + 3),
     (20, 12, 20, "int16", 12, 20 * 3000 + 7), (10, 12, 10, "int16", 12, 10 * 5000 + 3), (40, 12, 40, "int16", 12, 40 * 2100 + 11),
-    (56, 12, 56, "cf32", 0, 56 * 1200 + 5), (128, 12, 64, "cf32", 0, (1 << 16) + 17), (256, 8, 256, "cf32", 0, (1 << 17) + 100)])
+    (56, 12, 56, "cf32", 0, 56 * 1200 + 5), (128, 12, 64, "cf32", 0, (1 << 16) + 17), (256, 8, 256, "cf32", 0, (1 << 17) + 100),
+    (560, 12, 560, "cf32", 0, 560 * 130 + 77), (1024, 16, 1024, "cf32", 0, (1 << 18) + 300)])
 def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     rng = np.random.default_rng(n + M)
     if fmt == "cf32":
@@ -97,7 +98,8 @@ def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     h = rng.standard_normal(M * P).astype(np.float32) / np.float32(M)
     with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=max(bw, 1)) as ch:
         y = ch(iq)
-        if (M, P, D) in ((64, 12, 64), (56, 12, 56), (128, 12, 64), (256, 8, 256), (8, 12, 8)):  # fused in every format
+        if (M, P, D) in ((64, 12, 64), (56, 12, 56), (128, 12, 64), (256, 8, 256), (8, 12, 8), (560, 12, 560),
+                         (1024, 16, 1024)):  # fused in every format
             assert ch.last_kernel.startswith("pfb_fast"), ch.last_kernel
     want = oracle_run(oracle, iq, h, M, P, D, bw, fmt)
     assert rel(y, want) < REL_TOL

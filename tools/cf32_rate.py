@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sdr_channelizer_amd import Channelizer, design_prototype
 
-for M, P, D, log2n in ((56, 12, 56, 27), (64, 12, 64, 28), (128, 12, 64, 27), (256, 8, 256, 28)):
+for M, P, D, log2n in ((56, 12, 56, 27), (64, 12, 64, 28), (128, 12, 64, 27), (256, 8, 256, 28), (560, 12, 560, 27), (1024, 16, 1024, 28)):
     n = (1 << log2n) // D * D
     iq = (torch.randn(n, 2, device="cuda") * 0.3)
     with Channelizer(M, taps=design_prototype(M, P), decimation=D, sample_format="cf32") as ch:
