@@ -29,6 +29,12 @@ def _out_buffer(capacity: int):
     return buf
 
 
+def _take(out, n: int):
+    """A copy of the first n records.  Through a byte view: numpy copies a structured array field by field (0.25 ms for
+    24 000 PDWs), a byte array at memcpy speed."""
+    return out[:n].view(np.uint8).copy().view(PDW_DTYPE)
+
+
 def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decimation: int | None = None,
                  snr_threshold_db: float = 15.0, matlab_quirks: bool = True, capacity: int = 1 << 20,
                  return_noise_floor: bool = False, device: int = -1, channel_major: bool = False,
@@ -74,7 +80,7 @@ def extract_pdws(y, fs_in: float, fc: float, sample_start_time: float, *, decima
     n = int(count.value)
     if n > capacity:
         raise OverflowError(f"{n} pulses found, capacity {capacity}")
-    return (out[:n].copy(), nf) if return_noise_floor else out[:n].copy()
+    return (_take(out, n), nf) if return_noise_floor else _take(out, n)
 
 
 def pdws_from_iq_file(channelizer, path: str, *, snr_threshold_db: float = 15.0, matlab_quirks: bool = True,
@@ -102,7 +108,7 @@ def pdws_from_iq_file(channelizer, path: str, *, snr_threshold_db: float = 15.0,
     n = int(count.value)
     if n > capacity:
         raise OverflowError(f"{n} pulses found, capacity {capacity}")
-    return (out[:n].copy(), nf, info) if return_noise_floor else (out[:n].copy(), info)
+    return (_take(out, n), nf, info) if return_noise_floor else (_take(out, n), info)
 
 
 def raw_pdws_from_iq_file(path: str, *, snr_threshold_db: float = 18.0, trailing_threshold_db: float = 3.0,
@@ -123,7 +129,7 @@ def raw_pdws_from_iq_file(path: str, *, snr_threshold_db: float = 18.0, trailing
     n = int(count.value)
     if n > capacity:
         raise OverflowError(f"{n} pulses found, capacity {capacity}")
-    return (out[:n].copy(), nf.value, info) if return_noise_floor else (out[:n].copy(), info)
+    return (_take(out, n), nf.value, info) if return_noise_floor else (_take(out, n), info)
 
 
 def extract_pdws_raw(iq, fs: float, fc: float, sample_start_time: float, *, bit_width: int = 12,
@@ -168,4 +174,4 @@ def extract_pdws_raw(iq, fs: float, fc: float, sample_start_time: float, *, bit_
     k = int(count.value)
     if k > capacity:
         raise OverflowError(f"{k} pulses found, capacity {capacity}")
-    return (out[:k].copy(), nf.value) if return_noise_floor else out[:k].copy()
+    return (_take(out, k), nf.value) if return_noise_floor else _take(out, k)
