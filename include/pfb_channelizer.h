@@ -288,6 +288,14 @@ int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double*
  * every wave owning rows_per_wave consecutive 256-byte rows (even, >= 2).  What the memory system gives that byte mix
  * depends on how short-lived the waves are (0.78 / 0.75 of the nominal 8 TB/s at 2 rows, 0.63 / 0.64 at 512): the
  * bound bench.py prints next to each shape's fraction. */
+/* Timing probe of the fused PDW screen (schedule 12 -- not selectable through PFB_OPT_SCHEDULE, it needs the screen's tables; measured slower than the
+ * separate bracket pass) with
+ * caller-made thresholds: thr4 = M x (below-bracket, above-bracket, under-threshold, over-threshold) float32 limits on
+ * |y|^2, host memory.  Device buffers; frames must be a multiple of 64.  counters[3]: candidates parked, samples
+ * listed as undecided, flags.  Shapes without the fused instantiation: PFB_ERR_UNSUPPORTED. */
+int pfb_probe_pdw_fused(pfb_handle* handle, const void* d_iq, uint64_t num_samples, void* d_out, uint64_t capacity_frames,
+                        const float* thr4, int iters, double* ms_per_call, uint64_t* counters);
+
 int pfb_measure_mix_copy(int device_id, uint64_t bytes_in, uint32_t write_ratio, uint32_t rows_per_wave, int iters,
                          double* bytes_per_sec);
 

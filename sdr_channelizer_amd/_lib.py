@@ -87,7 +87,7 @@ EXPORTS = (
     "pfb_measure_stream_copy", "pfb_get_kernel_times", "pfb_host_alloc", "pfb_host_free", "pfb_pdw_extract", "pfb_pdw_extract_raw", "pfb_pdw_from_iq_file", "pfb_pdw_raw_from_iq_file", "pfb_pdw_last_error_detail", "pfb_pdw_release_workspace", "pfb_pdw_last_noise_floor_path",
     "pfb_iq_parse_header", "pfb_iq_fill_packet", "pfb_iq_filename",
     "pfb_shard_attach", "pfb_halo_samples", "pfb_shard_head_frames", "pfb_halo_recv_buffer", "pfb_process_shard_async",
-    "pfb_center_frequencies_ordered", "pfb_selftest_exception_guard", "pfb_measure_mix_copy",
+    "pfb_center_frequencies_ordered", "pfb_selftest_exception_guard", "pfb_measure_mix_copy", "pfb_probe_pdw_fused",
 )
 
 _lib = None
@@ -175,6 +175,8 @@ def load() -> C.CDLL:
     lib.pfb_pdw_last_noise_floor_path.restype = C.c_int
     lib.pfb_measure_stream_copy.argtypes = [C.c_int, u64, C.c_int, C.POINTER(C.c_double)]
     lib.pfb_measure_mix_copy.argtypes = [C.c_int, u64, u32, u32, C.c_int, C.POINTER(C.c_double)]
+    lib.pfb_probe_pdw_fused.argtypes = [C.c_void_p, C.c_void_p, u64, C.c_void_p, u64, C.POINTER(C.c_float), C.c_int,
+                                        C.POINTER(C.c_double), C.POINTER(u64)]
     lib.pfb_iq_parse_header.argtypes = [vp, C.c_size_t, C.POINTER(PfbIqInfo)]
     lib.pfb_iq_fill_packet.argtypes = [C.POINTER(PfbIqPacket), u32, u64, u32, u32, C.c_float, u32, u32,
                                        C.c_char_p, C.c_char_p, C.c_double]

@@ -64,6 +64,7 @@ struct StateHeader {
 }  // namespace
 
 struct pfb_handle {
+  const pfb::PdwFuse* pdw_fuse = nullptr;  // set while a fused channelize + PDW screen call is running (schedule 12)
   int M = 0, P = 0, D = 0, off = 0;
   int fmt = 0, bit_width = 0, layout = 0;
   unsigned flags = 0;
@@ -238,6 +239,13 @@ int launch_frames(pfb_handle* h, const void* d_iq, uint64_t n, const void* hist,
     if (cm && !by_slabs)  // fused channel-major: 0 = sliding runs, 2 = tiles, 8 = short runs transposed in LDS, else the kernel's pick
       p.schedule = forced_fused ? h->opt_schedule : -1;
     if (by_tiles) p.schedule = 10;
+    if (h->pdw_fuse) {  // the PDW screen rides in the last pass: runs of exactly one 64-frame mask word
+      if (cm || !h->fast->pdw_fused_ok) return PFB_ERR_UNSUPPORTED;
+      p.schedule = 12;
+      p.pdw = h->pdw_fuse;
+      fpb = 64;
+      if (h->opt_xcd_remap < 0) p.xcd_remap = 0;
+    }
     if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
     if (p.schedule == 6 || p.schedule == 7) fpb = ((fpb + 2 * c - 1) / (2 * c)) * (2 * c);  // these kernels walk chunks in pairs
     if (p.schedule == 4 || p.schedule == 5) {
@@ -1244,6 +1252,76 @@ int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double*
   if (e1) (void)hipEventDestroy(e1);
   (void)hipFree(in);
   (void)hipFree(out);
+  return rc;
+  });
+}
+
+// Timing probe of the fused screen (schedule 12) with caller-made thresholds: thr4 = M x (a, b, c, d) float32 on the
+// host.  counters: [0] candidates parked, [1] undecided listed, [2] flags.  Buffers live for the call only.
+int pfb_probe_pdw_fused(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t cap_frames, const float* thr4,
+                        int iters, double* ms, uint64_t* counters) {
+  return pfb::abi_guard([&]() -> int {
+  if (!h || !d_iq || !d_out || !thr4 || !ms || iters < 1) return PFB_ERR_BAD_ARG;
+  if (!h->fast || !h->fast->pdw_fused_ok) return PFB_ERR_UNSUPPORTED;
+  DeviceGuard g(h->device);
+  const uint64_t F = frames_for(h, n);
+  if (F > cap_frames || F % 64) return PFB_ERR_BAD_ARG;
+  const uint64_t runs = F / 64;
+  const int cap = 384, und_cap = 1 << 20;
+  pfb::PdwFuse f{};
+  char* blob = nullptr;
+  auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t sz[] = {pad((size_t)h->M * 16), pad(runs * cap * 8), pad(runs * cap * 2), pad(runs * 4), pad(runs * h->M * 8),
+                       pad(runs * h->M * 8), pad(runs * h->M), pad((size_t)und_cap * 8), 256, 256, pad(sizeof(pfb::PdwFuse))};
+  size_t total = 0;
+  for (size_t b : sz) total += b;
+  HIP_TRY(hipMalloc((void**)&blob, total));
+  size_t o = 0;
+  auto take = [&](int i) { char* r = blob + o; o += sz[i]; return r; };
+  float4* d_thr = (float4*)take(0);
+  f.thr = d_thr;
+  f.cand_v = (float2*)take(1); f.cand_c = (unsigned short*)take(2); f.cand_n = (unsigned*)take(3);
+  f.f0 = (unsigned long long*)take(4); f.f1 = (unsigned long long*)take(5); f.below_run = (unsigned char*)take(6);
+  f.undecided = (unsigned long long*)take(7); f.und_n = (unsigned*)take(8); f.flags = (unsigned*)take(9);
+  pfb::PdwFuse* d_f = (pfb::PdwFuse*)take(10);
+  f.cap = cap; f.und_cap = und_cap;
+  int rc = PFB_OK;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float t = 0.f;
+  std::vector<unsigned> h_n;
+  hipError_t e = hipMemcpy(d_thr, thr4, (size_t)h->M * 16, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_f, &f, sizeof(f), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e != hipSuccess) { rc = hip_fail(e, "pfb_probe_pdw_fused setup"); goto out; }
+  h->pdw_fuse = d_f;
+  for (int it = -2; it < iters && rc == PFB_OK; ++it) {
+    if (it == 0) (void)hipEventRecord(e0, h->stream);
+    (void)hipMemsetAsync(f.und_n, 0, 512, h->stream);  // und_n and flags
+    pfb_reset(h);
+    rc = enqueue(h, d_iq, n, d_out, F, (int64_t)F, 0);
+  }
+  h->pdw_fuse = nullptr;
+  (void)hipEventRecord(e1, h->stream);
+  (void)hipStreamSynchronize(h->stream);
+  if (rc == PFB_OK) {
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms = (double)t / iters;
+    if (counters) {
+      h_n.resize(runs);
+      unsigned un = 0, fl = 0;
+      (void)hipMemcpy(h_n.data(), f.cand_n, runs * 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&un, f.und_n, 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&fl, f.flags, 4, hipMemcpyDeviceToHost);
+      uint64_t tot = 0;
+      for (unsigned v : h_n) tot += v;
+      counters[0] = tot; counters[1] = un; counters[2] = fl;
+    }
+  }
+out:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(blob);
   return rc;
   });
 }

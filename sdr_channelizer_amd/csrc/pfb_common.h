@@ -29,6 +29,22 @@ static inline int abi_guard(F&& body) noexcept {
 //   sample index of (row r, column c) = r*D + base + c,   c = 0..D-1
 // relative to in[0]; negative indices live in the history buffer, whose last
 // element hist[hist_samples-1] is the sample just before in[0].
+// PDW extraction fused into the channelizer's last pass (pfb_overlap_pdw_kernel; the consumer is pfb_pdw.hip): where the
+// float32 screens of every output column live and where a run's findings go.  Device-resident, one per extraction.
+struct PdwFuse {
+  const float4* thr;             // [M] per OUTPUT column: (below the bracket if <, above it if >, under the threshold if <, over it if >)
+  float2* cand_v;                // [runs][cap] samples inside the bracket's zone, as stored
+  unsigned short* cand_c;        // [runs][cap] their columns
+  unsigned* cand_n;              // [runs] how many (may exceed cap: the run overflowed, flags |= 1)
+  unsigned long long* f0;        // [words][M] provisional comparison masks, one word per run and column
+  unsigned long long* f1;
+  unsigned char* below_run;      // [runs][M] samples surely below the bracket
+  unsigned long long* undecided; // samples inside the threshold's band: frame * M + column
+  unsigned* und_n;
+  unsigned* flags;               // 1: a run's list overflowed, 4: the undecided list overflowed
+  int cap, und_cap;
+};
+
 struct KernelParams {
   const void* in;          // this call's samples (device), cfg.sample_format
   const void* hist;        // hist_samples samples of history (device)
@@ -59,6 +75,7 @@ struct KernelParams {
   int grid_override;       // schedule 1: workgroups to launch (0 = what is resident at once)
   void* scratch;           // schedule 10: scratch_slots x 2 tiles of cm_tile_frames x M complex64, a slot per resident workgroup
   int scratch_slots;
+  const PdwFuse* pdw;      // pfb_overlap_pdw_kernel only
 };
 
 // sample traits -----------------------------------------------------------------
@@ -109,6 +126,7 @@ struct FastKernelInfo {
   bool channel_major_ok;   // has a channel-major instantiation
   int magnitude_schedule;  // measured best schedule with PFB_FLAG_MAGNITUDE, -1 = default_schedule
   int cm_tile_frames;      // > 0: the team kernel has a fused channel-major route (schedule 10) with tiles of this many frames
+  bool pdw_fused_ok;       // has the instantiation with the PDW screen in its last pass (schedule 12)
 };
 const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant = 0, bool channel_major = false);
 

@@ -419,9 +419,84 @@ struct FastKernel {
   }
 
   // out_base / frames_lim: the last pass's destination when it is not p.out (the team kernel's scratch tile)
-  template <int I>
+  // ---- PDW screen fused into the last pass (pfb_overlap_pdw_kernel) ----------------------------------------------
+  // A run of this kernel is 64 frames = one comparison-mask word per column.  Lane (g = tid / IPF, kk = tid % IPF)
+  // sees frames g + C/2... of every chunk for its R columns kk + k KK: per column 16 of the word's 64 frames, bit
+  // j = (frame in run) / 4 of a 16-bit field; the four lane groups are interleaved into the word when the run ends.
+  struct PdwLane {
+    unsigned ov[4];    // "surely over the threshold" bits, two columns per register
+    unsigned nb[2];    // "surely below the bracket" counts, 8-bit fields, four columns per register
+    unsigned cnt;      // entries this run has appended to its candidate list (uniform over the wave)
+    int run;           // run index = word index
+  };
+  static constexpr bool kPdwOk = NT == 64 && K::NP == 2 && !K::PINGPONG && K::POW2 && K::R(K::NP - 1) == 8 &&
+                                 M / K::R(K::NP - 1) == 16 && C == 8 && M <= 65535 && K::FMT != PFB_FMT_CF32;
+
+  PFB_DEV void pdw_visit(const KernelParams& p, PdwLane& pl, const float4* thr, v2f v, int k, int col, int j, long long f) {
+    const PdwFuse& q = *p.pdw;
+    const float m32 = __builtin_fmaf(v.x, v.x, v.y * v.y);
+    const float4 t = thr[col];
+    pl.nb[k >> 2] += (unsigned)(m32 < t.x) << (8 * (k & 3));
+    const bool zone = !(m32 < t.x) && !(m32 > t.y);
+    const unsigned long long bal = __ballot(zone);
+    if (bal) {  // park the sample, as stored, in the run's list: slots by ballot, no atomics
+      const unsigned pos = pl.cnt + (unsigned)__popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull));
+      if (zone && pos < (unsigned)q.cap) {
+        const unsigned at = (unsigned)pl.run * (unsigned)q.cap + pos;  // runs * cap < 2^32 (checked by the host)
+        q.cand_v[at] = make_float2(v.x, v.y);
+        q.cand_c[at] = (unsigned short)col;
+      }
+      pl.cnt += (unsigned)__popcll(bal);
+    }
+    pl.ov[k >> 1] |= (unsigned)(m32 > t.w) << (j + 16 * (k & 1));
+    const bool band = !(m32 < t.z) && !(m32 > t.w);
+    if (__ballot(band)) {  // inside the threshold's zone (a handful per record): listed, classified exactly once the median is known
+      if (band) {
+        const unsigned u = atomicAdd(q.und_n, 1u);
+        if (u < (unsigned)q.und_cap) q.undecided[u] = (unsigned long long)f * (unsigned long long)M + (unsigned)col;
+        else atomicOr(q.flags, 4u);
+      }
+    }
+  }
+
+  // the run is over: interleave the four lane groups' 16-bit fields into the word of every column, add up the counts
+  PFB_DEV void pdw_finish_run(const KernelParams& p, const PdwLane& pl, int tid, long long f_begin, long long f_end, int shift) {
+    const PdwFuse& q = *p.pdw;
+    constexpr int R = K::R(K::NP - 1), KK = K::K(K::NP - 1), IPF = M / R;
+    const int g = tid / IPF, kk = tid % IPF;
+    const long long nfr = f_end - f_begin;
+    const unsigned long long pad = nfr >= 64 ? 0ull : ~0ull << nfr;  // frames past the end: identity (f0 = 0, f1 = 1)
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      unsigned long long x = (pl.ov[k >> 1] >> (16 * (k & 1))) & 0xffffu;  // bit j -> bit 4 j + g
+      x = (x | (x << 24)) & 0x000000FF000000FFull;
+      x = (x | (x << 12)) & 0x000F000F000F000Full;
+      x = (x | (x << 6)) & 0x0303030303030303ull;
+      x = (x | (x << 3)) & 0x1111111111111111ull;
+      x <<= g;
+      x |= __shfl_xor(x, IPF);
+      x |= __shfl_xor(x, 2 * IPF);
+      unsigned nbk = (pl.nb[k >> 2] >> (8 * (k & 3))) & 0xffu;
+      nbk += __shfl_xor(nbk, IPF);
+      nbk += __shfl_xor(nbk, 2 * IPF);
+      if (g == 0) {
+        int col = kk + k * KK + shift;
+        col = col >= M ? col - M : col;
+        q.f0[(size_t)pl.run * M + col] = x & ~pad;
+        q.f1[(size_t)pl.run * M + col] = x | pad;
+        q.below_run[(size_t)pl.run * M + col] = (unsigned char)nbk;
+      }
+    }
+    if (tid == 0) {
+      q.cand_n[pl.run] = pl.cnt;
+      if (pl.cnt > (unsigned)q.cap) atomicOr(q.flags, 1u);
+    }
+  }
+
+  template <int I, bool PDW = false>
   PFB_DEV void pass(const KernelParams& p, float2* src, float2* dst, int tid, long long f0,
-                    const v2f (&tw)[2][16], float2* out_base = nullptr, long long frames_lim = -1) {
+                    const v2f (&tw)[2][16], float2* out_base = nullptr, long long frames_lim = -1, PdwLane* pl = nullptr,
+                    const float4* thr = nullptr, long long f_run = 0) {
     float2* const p_out = out_base ? out_base : p.out;
     const long long p_frames = frames_lim >= 0 ? frames_lim : p.frames;
     constexpr int R = K::R(I), S = K::S(I), KK = K::K(I), RS = K::RS(I);
@@ -566,7 +641,9 @@ struct FastKernel {
             // lane exchange a correct layout needs (4 DPP moves per pair): not store-issue-bound, left alone)
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-              store_c64(slot(row, k), derot(x[k], k), p.nontemporal);
+              const v2f v = derot(x[k], k);
+              store_c64(slot(row, k), v, p.nontemporal);
+              if constexpr (PDW) pdw_visit(p, *pl, thr, v, k, col_of(kk + k * KK), (int)((f - f_run) >> 2), f);
             }
           }
         }
@@ -688,9 +765,9 @@ struct FastKernel {
 
   // FIR of C frames from the window x (x[i] = row f0-(W-1)+i) into LDS, then the FFT passes and the
   // stores.  u_{p_lo + D ph}[t] = sum_q h[ph + OS q] * x[row t - ph - OS q]: one v_pk_fma_f32 per tap.
-  template <bool WAVE_LOCAL = false, bool TRANSPOSED = false>
+  template <bool WAVE_LOCAL = false, bool TRANSPOSED = false, bool PDW = false>
   PFB_DEV void fir_fft_store(const KernelParams& p, const Consts& k, const v2f (&x)[NW][CPT], float2* lds, int tid,
-                             long long f0) {
+                             long long f0, PdwLane* pl = nullptr, const float4* thr = nullptr, long long f_run = 0) {
     float2* buf0 = lds;
     float2* buf1 = K::PINGPONG ? lds + K::BUF : lds;
 #pragma unroll
@@ -724,7 +801,7 @@ struct FastKernel {
       last_pass_transposed(p, buf1, tid, f0);
       return;
     } else if constexpr (K::NP == 2) {
-      pass<1>(p, buf1, nullptr, tid, f0, k.tw);
+      pass<1, PDW>(p, buf1, nullptr, tid, f0, k.tw, nullptr, -1, pl, thr, f_run);
     } else {
       pass<1>(p, buf1, buf0, tid, f0, k.tw);
       team_sync<WAVE_LOCAL>();
@@ -768,10 +845,19 @@ struct FastKernel {
   }
 
   // ---- schedule A: sliding window over a long contiguous run per workgroup ---------------------
-  template <bool INTERIOR>
-  PFB_DEV void run_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end) {
+  template <bool INTERIOR, bool PDW = false>
+  PFB_DEV void run_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end,
+                        const float4* thr = nullptr) {
     const int tid = threadIdx.x;
     const int c0 = tid * CPT;
+    PdwLane pl;
+    if constexpr (PDW) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pl.ov[i] = 0u;
+      pl.nb[0] = pl.nb[1] = 0u;
+      pl.cnt = 0u;
+      pl.run = (int)(f_begin / 64);
+    }
     // uniform pointer to (row f_begin-(W-1), column 0); only dereferenced on the INTERIOR path
     const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
     v2f x[NW][CPT];
@@ -797,13 +883,14 @@ struct FastKernel {
         const long long rel = (f0 - f_begin) + C + (W - 1);
         load_rows<INTERIOR>(p, run_ptr, f0 + C, rel, c0, raw, rf);
       }
-      fir_fft_store(p, k, x, lds, tid, f0);
+      fir_fft_store<false, false, PDW>(p, k, x, lds, tid, f0, &pl, thr, f_begin);
       // slide the window by C rows
 #pragma unroll
       for (int i = 0; i < W - 1; ++i)
 #pragma unroll
         for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
     }
+    if constexpr (PDW) pdw_finish_run(p, pl, tid, f_begin, f_end, (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0);
   }
 
   PFB_DEV void run(const KernelParams& p, float2* lds) {
@@ -871,9 +958,18 @@ struct FastKernel {
     }
   }
 
-  template <bool INTERIOR>
-  PFB_DEV void run_overlap_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end) {
+  template <bool INTERIOR, bool PDW = false>
+  PFB_DEV void run_overlap_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end,
+                                const float4* thr = nullptr) {
     static_assert(NT == 64 && K::NP == 2 && !K::PINGPONG, "single-wave two-pass plans");
+    PdwLane pl;
+    if constexpr (PDW) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pl.ov[i] = 0u;
+      pl.nb[0] = pl.nb[1] = 0u;
+      pl.cnt = 0u;
+      pl.run = (int)(f_begin / 64);
+    }
     const int tid = threadIdx.x;
     const int c0 = tid * CPT;
     const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
@@ -923,14 +1019,37 @@ struct FastKernel {
       pass<0>(p, cur, cur, tid, f_begin + ci * C, k.tw);
       slide();
       team_sync<true>();
-      pass<1>(p, cur, nullptr, tid, f_begin + ci * C, k.tw);
+      pass<1, PDW>(p, cur, nullptr, tid, f_begin + ci * C, k.tw, nullptr, -1, &pl, thr, f_begin);
       fir_write(k, acc, nxt, tid);
       team_sync<true>();
       float2* t = cur; cur = nxt; nxt = t;
     }
     pass<0>(p, cur, cur, tid, f_begin + (nchunks - 1) * C, k.tw);
     team_sync<true>();
-    pass<1>(p, cur, nullptr, tid, f_begin + (nchunks - 1) * C, k.tw);
+    pass<1, PDW>(p, cur, nullptr, tid, f_begin + (nchunks - 1) * C, k.tw, nullptr, -1, &pl, thr, f_begin);
+    if constexpr (PDW) pdw_finish_run(p, pl, tid, f_begin, f_end, (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0);
+  }
+
+  // the same runs with the PDW screen in the last pass; thr: this workgroup's copy of the per-column screens in LDS
+  PFB_DEV void run_overlap_pdw(const KernelParams& p, float2* lds, float4* thr) {
+    static_assert(kPdwOk, "shape of the fused screen");
+    long long run = blockIdx.x;
+    if (p.xcd_remap) {
+      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
+      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
+    }
+    const long long f_begin = run * 64;
+    if (f_begin >= p.frames) return;
+    const long long f_last = f_begin + 64;
+    const long long f_end = f_last < p.frames ? f_last : p.frames;
+    for (int c = threadIdx.x; c < M; c += NT) thr[c] = p.pdw->thr[c];
+    Consts k;
+    setup(p, threadIdx.x, k);
+    team_sync<true>();
+    const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_last <= p.frames);
+    // the plain sliding kernel, not the software-pipelined one: that one has no registers left for the screen (105 spilled)
+    if (interior) run_impl<true, true>(p, k, lds, f_begin, f_end, thr);
+    else run_impl<false, true>(p, k, lds, f_begin, f_end, thr);
   }
 
   PFB_DEV void run_overlap(const KernelParams& p, float2* lds) {
@@ -2054,6 +2173,14 @@ __global__ void __launch_bounds__(K::NT, (K::MIN_WAVES > 2 ? K::MIN_WAVES - 1 : 
 template <class K>
 constexpr bool kOverlapOk = K::NT == 64 && K::NP == 2 && !K::PINGPONG;
 
+// schedule 12: schedule 11's runs of 64 frames with the PDW screen fused into the last pass (KernelParams::pdw)
+template <class K>
+__global__ void __launch_bounds__(K::NT, (K::MIN_WAVES > 2 ? K::MIN_WAVES - 1 : K::MIN_WAVES)) pfb_overlap_pdw_kernel(const KernelParams p) {
+  __shared__ float2 lds[2 * K::BUF];
+  __shared__ float4 thr[K::M];
+  FastKernel<K>::run_overlap_pdw(p, lds, thr);
+}
+
 template <class K>
 __global__ void __launch_bounds__(K::NT, (K::MIN_WAVES > 3 ? 3 : K::MIN_WAVES)) pfb_strided_kernel(const KernelParams p) {
   __shared__ float2 lds[K::LDS_ELEMS];
@@ -2315,6 +2442,14 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
         if (p.tile_waves >= 8) return launch_pairs_sliding<K, 8, 4>(p, s);
       }
       return launch_pairs_sliding<K, 6, 3>(p, s);
+    }
+  }
+  if constexpr (kOverlapOk<K> && FastKernel<K>::kPdwOk) {  // schedule 11 with the PDW screen in the last pass
+    if (p.schedule == 12) {
+      if (!p.pdw || p.layout != PFB_LAYOUT_FRAME_MAJOR || (p.flags & PFB_FLAG_MAGNITUDE)) return hipErrorInvalidValue;
+      const long long nb = (p.frames + 63) / 64;
+      hipLaunchKernelGGL(pfb_overlap_pdw_kernel<K>, dim3((unsigned)nb), dim3(K::NT), 0, s, p);
+      return hipGetLastError();
     }
   }
   if constexpr (kOverlapOk<K>) {  // sliding runs, FIR of the next chunk scheduled into the FFT of this one

@@ -708,3 +708,35 @@ def test_cpp_host_loop_without_python(oracle, tmp_path):
         pdws = np.fromfile(path + ".pdw", dtype=PDW_DTYPE)
         ref_pdws = extract_pdws(got, 56e6, 915e6, 0.0)
         assert len(pdws) == len(ref_pdws) > 0 and np.array_equal(pdws, ref_pdws)
+
+
+def test_fused_pdw_screen_probe_counts():
+    """pfb_probe_pdw_fused (schedule 12: the PDW screen inside the M=128 D=64 kernel's last pass -- a measurement, slower
+    than the separate pass): the output is the ordinary one and the candidates it parks are the
+    samples inside the bracket's float32 zone."""
+    import ctypes as C
+    import torch
+    from sdr_channelizer_amd import design_prototype
+    M, P, D, n = 128, 12, 64, 1 << 22
+    iq = synth.pulsed_iq_torch(n, 12, device="cuda")
+    with Channelizer(M, taps=design_prototype(M, P), decimation=D, bit_width=12, fftshift=True) as ch:
+        want = ch(iq).clone()
+        m2 = want.real.float() ** 2 + want.imag.float() ** 2
+        med = m2.median(dim=0).values
+        thr = torch.stack([med * 0.97, med * 1.03, med * 900.0, med * 1100.0], dim=1).cpu().numpy().astype(np.float32)
+        y = torch.zeros_like(want)
+        ms, cnt = C.c_double(0.0), (C.c_uint64 * 3)()
+        rc = L.load().pfb_probe_pdw_fused(ch._h, C.c_void_p(iq.data_ptr()), n, C.c_void_p(y.data_ptr()), n // D,
+                                          thr.ctypes.data_as(C.POINTER(C.c_float)), 1, C.byref(ms), cnt)
+        assert rc == L.PFB_OK
+        assert torch.equal(y, want)
+        t = torch.from_numpy(thr).cuda()
+        zone = int(((m2 >= t[:, 0]) & (m2 <= t[:, 1])).sum())
+        band = int(((m2 >= t[:, 2]) & (m2 <= t[:, 3])).sum())
+        assert abs(int(cnt[0]) - zone) <= max(4, zone // 5000)   # fma vs mul + add at the zone's edges
+        assert abs(int(cnt[1]) - band) <= max(4, band // 1000)
+        assert cnt[2] == 0
+    with Channelizer(64, taps=design_prototype(64, 12)) as ch64:   # no fused instantiation
+        rc = L.load().pfb_probe_pdw_fused(ch64._h, C.c_void_p(iq.data_ptr()), 1 << 12, C.c_void_p(y.data_ptr()), 64,
+                                          thr.ctypes.data_as(C.POINTER(C.c_float)), 1, C.byref(ms), cnt)
+        assert rc == L.PFB_ERR_UNSUPPORTED
