@@ -1075,7 +1075,7 @@ struct ChanSrc {  // F x M channelizer output, frame-major complex64
 template <int FMT>
 struct RawSrc {
   static constexpr int kCache = kPulseCacheRaw;
-  static constexpr int kThreads = 256;
+  static constexpr int kThreads = 512;  // 256: 0.84 ms for 4794 pulses of 5600 samples, 512: 0.66, 1024: 1.09 (one workgroup per CU)
   const void* p;
   double inv_scale;  // 2^-(bit_width-1); 1 for cf32
   __device__ __forceinline__ void reim(long long i, double& re, double& im) const {
