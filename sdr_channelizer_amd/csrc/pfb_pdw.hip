@@ -1264,13 +1264,16 @@ constexpr int kRawBits = 11, kRawBins = 1 << kRawBits;
 
 // one digit pass of the radix select of the stream's median |x|^2 key: digit = (key >> shift) & (bins-1)
 // among keys whose bits above the digit equal `prefix`
+// below_out (optional): also count the keys whose bits above the digit are SMALLER than prefix's -- what a pass that
+// starts from a predicted prefix needs to turn the stream's rank into a rank inside the bucket
 template <class Src, bool VEC>
 __global__ void __launch_bounds__(256) pdw_raw_hist_kernel(Src src, long long n, int shift, unsigned bins_mask,
                                                            unsigned long long prefix, unsigned long long prefix_mask,
-                                                           unsigned* hist) {
+                                                           unsigned* hist, unsigned long long* below_out) {
   __shared__ unsigned h[kRawBins];
   for (int i = threadIdx.x; i < kRawBins; i += 256) h[i] = 0u;
   __syncthreads();
+  unsigned long long nbelow = 0ull;
   const long long step = (long long)gridDim.x * 1024;
   for (long long i0 = (long long)blockIdx.x * 1024; i0 < n; i0 += step) {  // four samples per thread in flight
     unsigned long long k[4];
@@ -1288,11 +1291,26 @@ __global__ void __launch_bounds__(256) pdw_raw_hist_kernel(Src src, long long n,
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) hist_add(h, (unsigned)(k[u] >> shift) & bins_mask, in[u] && ((k[u] & prefix_mask) == prefix));
+    for (int u = 0; u < 4; ++u) {
+      hist_add(h, (unsigned)(k[u] >> shift) & bins_mask, in[u] && ((k[u] & prefix_mask) == prefix));
+      nbelow += (unsigned long long)(in[u] && (k[u] & prefix_mask) < prefix);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < kRawBins; i += 256)
     if (h[i]) atomicAdd(&hist[i], h[i]);
+  if (below_out) {
+    for (int d = 32; d > 0; d >>= 1) nbelow += __shfl_xor(nbelow, d);
+    if ((threadIdx.x & 63) == 0 && nbelow) atomicAdd(below_out, nbelow);
+  }
+}
+
+// keys of ns samples spread over the stream (hashed positions, as the channelized sample): the host predicts the
+// median's leading digits from them
+template <class Src>
+__global__ void __launch_bounds__(256) pdw_raw_sample_kernel(Src src, long long stride, int ns, unsigned long long* keys) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q < ns) keys[q] = src.key(sample_row(q, stride));
 }
 
 // number of keys below `pivot` and the largest of them (the lower middle value of an even-length median)
@@ -1860,20 +1878,65 @@ int extract_raw(const void* d_iq, long long n, double inv_scale, double fs, doub
   std::vector<unsigned> h_hist(kRawBins);
   unsigned long long prefix = 0ull, rank = (unsigned long long)(n / 2), h_pair[2] = {0ull, 0ull};
   double nf = 0.0, lead = 0.0, trail = 0.0;
-  for (int ps = 0; ps < npass; ++ps) {
+  // The leading digits of the median are predictable: the keys of a few thousand samples spread over the stream bracket
+  // it (5 sigma either side of the sample's middle), and the digits both bracket ends share are, almost surely, the
+  // median's.  The select starts below them -- for noise-dominated int16 data the first two of the three passes see
+  // every key in one bucket -- and the first pass it does run also counts the keys below the predicted bucket, which
+  // both turns the rank into a rank inside the bucket and PROVES the prediction (the rank must fall inside); if it
+  // does not, the select starts over from the top.
+  int first_pass = 0;
+  if (n >= (1ll << 22)) {
+    constexpr int kNs = 4096;
+    const long long stride = n / kNs;
+    std::vector<unsigned long long> sk(kNs);
+    unsigned long long* d_sk = reinterpret_cast<unsigned long long*>(d_hist + kRawBins);  // room behind the histogram (see the caller)
+    hipLaunchKernelGGL(pdw_raw_sample_kernel<RawSrc<FMT>>, dim3(kNs / 256), dim3(256), 0, st, src, stride, kNs, d_sk);
+    PDW_TRY(hipGetLastError());
+    PDW_TRY(hipMemcpyAsync(sk.data(), d_sk, kNs * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    PDW_TRY(hipStreamSynchronize(st));
+    const int delta = (int)std::ceil(2.5 * std::sqrt((double)kNs)) + 2;
+    std::nth_element(sk.begin(), sk.begin() + (kNs / 2 - delta), sk.end());
+    const unsigned long long k_lo = sk[kNs / 2 - delta];
+    std::nth_element(sk.begin(), sk.begin() + (kNs / 2 + delta), sk.end());
+    const unsigned long long k_hi = sk[kNs / 2 + delta];
+    while (first_pass < npass - 1) {  // passes whose digit (and everything above) both bracket ends share
+      const int sh = pass[first_pass].shift;
+      if ((k_lo >> sh) != (k_hi >> sh)) break;
+      ++first_pass;
+    }
+    if (first_pass > 0) prefix = k_lo & (~0ull << pass[first_pass - 1].shift);
+  }
+  for (int ps = first_pass; ps < npass; ++ps) {
     const int top = pass[ps].shift + pass[ps].bits;
     const unsigned long long pmask = top >= 64 ? 0ull : (~0ull << top);
+    const bool check = first_pass > 0 && ps == first_pass;  // the first pass after a prediction
     PDW_TRY(hipMemsetAsync(d_hist, 0, kRawBins * sizeof(unsigned), st));
+    if (check) PDW_TRY(hipMemsetAsync(d_pair, 0, sizeof(unsigned long long), st));
     if (vec) {
       hipLaunchKernelGGL((pdw_raw_hist_kernel<RawSrc<FMT>, true>), dim3(grid), dim3(256), 0, st, src, n, pass[ps].shift,
-                         (1u << pass[ps].bits) - 1u, prefix, pmask, d_hist);
+                         (1u << pass[ps].bits) - 1u, prefix, pmask, d_hist, check ? d_pair : nullptr);
     } else {
       hipLaunchKernelGGL((pdw_raw_hist_kernel<RawSrc<FMT>, false>), dim3(grid), dim3(256), 0, st, src, n, pass[ps].shift,
-                         (1u << pass[ps].bits) - 1u, prefix, pmask, d_hist);
+                         (1u << pass[ps].bits) - 1u, prefix, pmask, d_hist, check ? d_pair : nullptr);
     }
     PDW_TRY(hipGetLastError());
     PDW_TRY(hipMemcpyAsync(h_hist.data(), d_hist, kRawBins * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    if (check) PDW_TRY(hipMemcpyAsync(h_pair, d_pair, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     PDW_TRY(hipStreamSynchronize(st));
+    if (check) {
+      unsigned long long in_bucket = 0;
+      for (int d = 0; d < kRawBins; ++d) in_bucket += h_hist[d];
+      const unsigned long long below_pred = h_pair[0];
+      h_pair[0] = 0ull;
+      if (below_pred > rank || rank - below_pred >= in_bucket) {  // the median is not in the predicted bucket: from the top
+        first_pass = 0;
+        prefix = 0ull;
+        rank = (unsigned long long)(n / 2);
+        ps = -1;
+        continue;
+      }
+      rank -= below_pred;
+    }
     unsigned long long cum = 0;
     int d = 0;
     const int last = (1 << pass[ps].bits) - 1;
@@ -1989,14 +2052,15 @@ static int pdw_extract_raw_impl(const void* iq, uint64_t num_samples, uint32_t s
   unsigned* d_hist;
   unsigned long long* d_pair;
   EdgeStage e{};
-  PDW_TRY(arena_reserve(ws, (mem == PFB_MEM_HOST ? padded((size_t)n * bps) : 0) + padded(kRawBins * sizeof(unsigned)) +
+  constexpr size_t kHistBytes = kRawBins * sizeof(unsigned) + 4096 * sizeof(unsigned long long);  // histogram + the sample's keys
+  PDW_TRY(arena_reserve(ws, (mem == PFB_MEM_HOST ? padded((size_t)n * bps) : 0) + padded(kHistBytes) +
                                 padded(2 * sizeof(unsigned long long)) + edge_stage_bytes(words, ntiles, 1)));
   if (mem == PFB_MEM_HOST) {
     char* own = take<char>(ws, (size_t)n * bps);
     PDW_TRY(hipMemcpyAsync(own, iq, (size_t)n * bps, hipMemcpyHostToDevice, st));
     d_iq = own;
   }
-  d_hist = take<unsigned>(ws, kRawBins);
+  d_hist = take<unsigned>(ws, kHistBytes / sizeof(unsigned));
   d_pair = take<unsigned long long>(ws, 2);
   e = take_edge_stage(ws, words, ntiles, 1, false);
   switch (sample_format) {

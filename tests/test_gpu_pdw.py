@@ -307,6 +307,43 @@ def test_raw_stream_at_recorder_size(oracle):
     compare(got, want, 56e6)
 
 
+def _sample_row(q, stride):
+    """the library's hashed sample position (pfb_pdw.hip: sample_row)"""
+    h = (q * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    h ^= h >> 29
+    return q * stride + (((h >> 40) * stride) >> 24)
+
+
+@pytest.mark.parametrize("fmt", ["int16", "cf32"])
+def test_raw_median_prediction_is_checked_not_trusted(oracle, fmt):
+    """Streams of >= 2^22 samples start their radix select below the digits a 4096-sample bracket shares.  Here the
+    sampled positions (the hash is deterministic) hold strong samples and everything else weak noise, so the prediction
+    is wrong in every leading digit: the counting pass must notice (the rank falls outside the predicted bucket) and the
+    select must start over -- same median, same PDWs as the oracle.  A second stream, ordinary, takes the shortcut."""
+    n = 1 << 22
+    rng = np.random.default_rng(3)
+    pos = np.array([_sample_row(q, n // 4096) for q in range(4096)])
+    for adversarial in (True, False):
+        if fmt == "int16":
+            iq = np.round(rng.standard_normal((n, 2)) * 12).astype(np.int16)
+            iq[200000:203000] += 900
+            if adversarial:
+                iq[pos] = 1500
+            x = (iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)) / 2048.0
+        else:
+            iq = (rng.standard_normal((n, 2)) * 0.006).astype(np.float32)
+            iq[200000:203000] += 0.45
+            if adversarial:
+                iq[pos] = 0.7
+            x = iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)
+            iq = (iq[:, 0] + 1j * iq[:, 1]).astype(np.complex64)
+        got, nf = extract_pdws_raw(iq, 56e6, 915e6, 0.0, return_noise_floor=True)
+        want, want_nf = oracle.extract_pdws_raw(x, 56e6, 915e6, 0.0, max_out=1 << 18)
+        assert nf == pytest.approx(want_nf, rel=1e-14), (fmt, adversarial)
+        assert len(want) >= 1
+        compare(got, want, 56e6)
+
+
 def test_raw_record_to_pdws_in_one_call(tmp_path):
     """pfb_pdw_raw_from_iq_file = one iteration of create_pdws.m's loop: the same PDWs as extract_pdws_raw on the
     record's payload with the header's fs / fc / bit width / start time; int16 and int8 records."""
