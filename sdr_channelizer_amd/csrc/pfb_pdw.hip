@@ -1044,6 +1044,97 @@ __global__ void __launch_bounds__(256) pdw_edges_kernel(const unsigned long long
   }
 }
 
+// One-column streams (the raw recorder stream) with long tiles: a thread per tile would be 16 384 threads walking 256
+// words each.  A WAVE per tile instead: lane l summarises words [l wpl, (l + 1) wpl) exactly as pdw_tilefn_kernel
+// summarises a tile (function + edge counts for both incoming states), the lanes' functions are scanned by composition
+// (shuffles), which gives every lane the state it is entered in on either trajectory, and the counts add up.
+__device__ __forceinline__ void lane_summary(const unsigned long long* f0, const unsigned long long* f1, long long w0, int wpl,
+                                             int& fn, unsigned (&c)[4]) {
+  int s0 = 0, s1 = 1;
+  c[0] = c[1] = c[2] = c[3] = 0u;
+  for (int j = 0; j < wpl; ++j) {
+    unsigned long long p0, p1;
+    word_scan(f0[w0 + j], f1[w0 + j], p0, p1);
+    const unsigned long long S0 = s0 ? p1 : p0, S1 = s1 ? p1 : p0;
+    const unsigned long long P0 = (S0 << 1) | (unsigned long long)s0, P1 = (S1 << 1) | (unsigned long long)s1;
+    c[0] += (unsigned)__popcll(S0 & ~P0); c[1] += (unsigned)__popcll(~S0 & P0);
+    c[2] += (unsigned)__popcll(S1 & ~P1); c[3] += (unsigned)__popcll(~S1 & P1);
+    s0 = (int)(S0 >> 63); s1 = (int)(S1 >> 63);
+  }
+  fn = s0 | (s1 << 1);
+}
+
+// exclusive scan of the lanes' functions by composition: the function that maps the tile's incoming state to the state
+// this lane is entered in; `total` = all 64 lanes composed
+__device__ __forceinline__ int lane_prefix_fn(int fn, int lane, int& total) {
+  int inc = fn;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int prev = __shfl_up(inc, d);
+    if (lane >= d) inc = compose_fn(prev, inc);
+  }
+  total = __shfl(inc, 63);
+  const int exc = __shfl_up(inc, 1);
+  return lane == 0 ? 0x2 : exc;  // identity for the first lane
+}
+
+__global__ void __launch_bounds__(256) pdw_tilefn_wave_kernel(const unsigned long long* f0, const unsigned long long* f1,
+                                                              long long ntiles, int tile_words, unsigned char* fn,
+                                                              ushort4* cnt) {
+  const int lane = threadIdx.x & 63;
+  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const int wpl = tile_words / 64;
+  int g;
+  unsigned c[4];
+  lane_summary(f0, f1, tile * tile_words + (long long)lane * wpl, wpl, g, c);
+  int total;
+  const int pre = lane_prefix_fn(g, lane, total);
+  const int in0 = pre & 1, in1 = (pre >> 1) & 1;  // the state this lane is entered in when the tile is entered in 0 / 1
+  unsigned a0 = in0 ? c[2] : c[0], e0 = in0 ? c[3] : c[1], a1 = in1 ? c[2] : c[0], e1 = in1 ? c[3] : c[1];
+  for (int d = 32; d > 0; d >>= 1) {
+    a0 += __shfl_xor(a0, d); e0 += __shfl_xor(e0, d);
+    a1 += __shfl_xor(a1, d); e1 += __shfl_xor(e1, d);
+  }
+  if (lane == 0) {
+    fn[tile] = (unsigned char)total;
+    cnt[tile] = make_ushort4((unsigned short)a0, (unsigned short)e0, (unsigned short)a1, (unsigned short)e1);
+  }
+}
+
+__global__ void __launch_bounds__(256) pdw_edges_wave_kernel(const unsigned long long* f0, const unsigned long long* f1,
+                                                             long long ntiles, int tile_words, const unsigned char* state_in,
+                                                             const unsigned long long* off_s, const unsigned long long* off_e,
+                                                             long long* starts, long long* ends) {
+  const int lane = threadIdx.x & 63;
+  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const int wpl = tile_words / 64;
+  const long long w0 = tile * tile_words + (long long)lane * wpl;
+  int g;
+  unsigned c[4];
+  lane_summary(f0, f1, w0, wpl, g, c);
+  int total;
+  const int pre = lane_prefix_fn(g, lane, total);
+  int s = (pre >> (int)state_in[tile]) & 1;  // the state this lane is really entered in
+  const unsigned ns = s ? c[2] : c[0], ne = s ? c[3] : c[1];
+  unsigned is = ns, ie = ne;  // inclusive prefix sums over the lanes
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned ps = __shfl_up(is, d), pe = __shfl_up(ie, d);
+    if (lane >= d) { is += ps; ie += pe; }
+  }
+  unsigned long long os = off_s[tile] + (is - ns), oe = off_e[tile] + (ie - ne);
+  for (int j = 0; j < wpl; ++j) {
+    const long long w = w0 + j;
+    unsigned long long p0, p1;
+    word_scan(f0[w], f1[w], p0, p1);
+    const unsigned long long S = s ? p1 : p0, P = (S << 1) | (unsigned long long)s;
+    unsigned long long up = S & ~P, down = ~S & P;
+    while (up) { starts[os++] = w * 64 + (__ffsll((long long)up) - 1); up &= up - 1; }
+    while (down) { ends[oe++] = w * 64 + (__ffsll((long long)down) - 1); down &= down - 1; }
+    s = (int)(S >> 63);
+  }
+}
+
 // make the per-tile offsets absolute: add the column bases (columns outermost = the reference's order)
 __global__ void pdw_rebase_kernel(int M, long long ntiles, unsigned long long* off_s, unsigned long long* off_e,
                                   const unsigned long long* base_s, const unsigned long long* base_e) {
@@ -1576,13 +1667,19 @@ int edges_and_pulses(Src src, int Mi, long long ntiles, int tile_words, const Ed
   unsigned* p_check = nullptr;
   unsigned long long total_s = 0, total_e = 0;
   const unsigned tblocks = (unsigned)((tm + 255) / 256);
+  const bool wave_tiles = Mi == 1 && tile_words >= 64 && tile_words % 64 == 0;  // one column, long tiles: a wave per tile
   PDW_TRY(pin_reserve(pin, (5 * (size_t)M + 1) * sizeof(unsigned long long)));
   h_tot = reinterpret_cast<unsigned long long*>(pin.p);
   h_base = h_tot + 2 * (size_t)M;
   p_nf = reinterpret_cast<double*>(h_base + 2 * (size_t)M);
   p_check = reinterpret_cast<unsigned*>(p_nf + M);
-  hipLaunchKernelGGL(pdw_tilefn_kernel, dim3(tblocks), dim3(256), 0, st, (const unsigned long long*)e.f0,
-                     (const unsigned long long*)e.f1, Mi, ntiles, tile_words, e.fn, e.cnt);
+  if (wave_tiles) {
+    hipLaunchKernelGGL(pdw_tilefn_wave_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, (const unsigned long long*)e.f0,
+                       (const unsigned long long*)e.f1, ntiles, tile_words, e.fn, e.cnt);
+  } else {
+    hipLaunchKernelGGL(pdw_tilefn_kernel, dim3(tblocks), dim3(256), 0, st, (const unsigned long long*)e.f0,
+                       (const unsigned long long*)e.f1, Mi, ntiles, tile_words, e.fn, e.cnt);
+  }
   if (Mi >= 32 && ntiles < 2048) {
     hipLaunchKernelGGL(pdw_tilescan_kernel<64>, dim3(Mi), dim3(64), 0, st, Mi, ntiles, (const unsigned char*)e.fn,
                        (const ushort4*)e.cnt, e.state, e.off_s, e.off_e, e.tot, e.tot + M);
@@ -1617,9 +1714,15 @@ int edges_and_pulses(Src src, int Mi, long long ntiles, int tile_words, const Ed
     PDW_TRY(hipMemcpyAsync(e.base, h_base, 2 * (size_t)M * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(pdw_rebase_kernel, dim3(tblocks), dim3(256), 0, st, Mi, ntiles, e.off_s, e.off_e,
                        (const unsigned long long*)e.base, (const unsigned long long*)(e.base + M));
-    hipLaunchKernelGGL(pdw_edges_kernel, dim3(tblocks), dim3(256), 0, st, (const unsigned long long*)e.f0,
-                       (const unsigned long long*)e.f1, Mi, ntiles, tile_words, (const unsigned char*)e.state,
-                       (const unsigned long long*)e.off_s, (const unsigned long long*)e.off_e, d_starts, d_ends);
+    if (wave_tiles) {
+      hipLaunchKernelGGL(pdw_edges_wave_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, (const unsigned long long*)e.f0,
+                         (const unsigned long long*)e.f1, ntiles, tile_words, (const unsigned char*)e.state,
+                         (const unsigned long long*)e.off_s, (const unsigned long long*)e.off_e, d_starts, d_ends);
+    } else {
+      hipLaunchKernelGGL(pdw_edges_kernel, dim3(tblocks), dim3(256), 0, st, (const unsigned long long*)e.f0,
+                         (const unsigned long long*)e.f1, Mi, ntiles, tile_words, (const unsigned char*)e.state,
+                         (const unsigned long long*)e.off_s, (const unsigned long long*)e.off_e, d_starts, d_ends);
+    }
     if (n_out > 0) {
       hipLaunchKernelGGL((pdw_pulse_kernel<Src, Src::kCache, Src::kThreads>), dim3((unsigned)n_out), dim3(Src::kThreads), 0, st, src, Mi, (const long long*)d_starts,
                          (const long long*)d_ends, (const unsigned long long*)e.base, (const unsigned long long*)(e.base + M),

@@ -307,6 +307,21 @@ def test_raw_stream_at_recorder_size(oracle):
     compare(got, want, 56e6)
 
 
+def test_raw_stream_long_tiles(oracle):
+    """2^26 samples and a ragged tail: the edge scan's tiles are 64 words long, which the one-column stream hands to a
+    wave per tile (pdw_tilefn_wave_kernel / pdw_edges_wave_kernel); a threshold low enough for tens of thousands of
+    detections spread over every tile."""
+    n = (1 << 26) + 12345
+    iq = synth.pulsed_iq_torch(n, 12, device="cuda")
+    got, nf = extract_pdws_raw(iq, 56e6, 915e6, 0.0, snr_threshold_db=4.0, trailing_threshold_db=2.0, return_noise_floor=True)
+    h = iq.cpu().numpy()
+    x = (h[:, 0].astype(np.float64) + 1j * h[:, 1].astype(np.float64)) / 2048.0
+    want, want_nf = oracle.extract_pdws_raw(x, 56e6, 915e6, 0.0, snr_db=4.0, trail_db=2.0, max_out=1 << 20)
+    assert nf == pytest.approx(want_nf, rel=1e-14)
+    assert len(want) >= 10000
+    compare(got, want, 56e6)
+
+
 def _sample_row(q, stride):
     """the library's hashed sample position (pfb_pdw.hip: sample_row)"""
     h = (q * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
