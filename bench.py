@@ -395,6 +395,17 @@ def main() -> None:
                         others[-1]["end_to_end"] = {"what": "channelizer kernel + PDW extraction of its matrix (host wall, results on the host)",
                                                     "pdw_extraction_ms": round(min(tp), 3), "pulses": int(len(pd)),
                                                     "total_ms": round(oms + min(tp), 3)}
+                        # the raw-stream extractor (create_pdws.m:30-105) on the same recorder stream, device-resident
+                        from sdr_channelizer_amd.pdw import extract_pdws_raw
+                        extract_pdws_raw(oiq, synth.FS, 915e6, 0.0, snr_threshold_db=12.0)
+                        tr = []
+                        for _ in range(3):
+                            torch.cuda.synchronize(dev)
+                            tq = time.perf_counter()
+                            pr = extract_pdws_raw(oiq, synth.FS, 915e6, 0.0, snr_threshold_db=12.0)
+                            tr.append((time.perf_counter() - tq) * 1e3)
+                        others[-1]["raw_stream_pdws"] = {"what": "PDW extraction straight from the recorder stream (create_pdws.m), host wall, results on the host",
+                                                         "samples": int(oiq.shape[0]), "ms": round(min(tr), 3), "pulses": int(len(pr))}
                     och.release()
                     del oiq, oout
                     torch.cuda.empty_cache()
