@@ -3,23 +3,29 @@
 // Restates the second half of /root/reference/matlab/create_pdws_channelized.m (lines 64-143) as
 // data-parallel passes over the F x M channelizer output (frame-major complex64, fftshift-ed):
 //
-//   noise floor  :73    exact per-channel median of |y|.  A hashed 1-in-k row sample brackets the median
-//                       (radix select of two sample ranks 5 sigma either side of the middle); ONE pass
-//                       over the data counts what lies below the bracket and gathers what lies inside
-//                       it (about 2 %), and a per-channel radix select over those candidates picks the
-//                       exact order statistics.  The count proves the bracket held the median; if it
-//                       did not (or the data are too tied / too short to sample) the full MSB-first
-//                       radix select runs instead: 8-bit digit histograms in LDS (lane = channel, so
-//                       LDS atomics never collide) until the bucket is small, then an exact finish.
+//   noise floor  :73    exact per-channel median of |y|.  A hashed 1-in-k row sample, read once, brackets the
+//                       median (per-channel select of two sample ranks 5 sigma either side of the middle); ONE
+//                       pass over the data -- every sample screened in float32, only the bracket's zone promoted
+//                       to float64 -- counts what lies below the bracket and gathers what lies inside it (about
+//                       2 %), and a per-channel select over those candidates picks the exact order statistics.
+//                       The count proves the bracket held the median; if it did not (or the data are too tied /
+//                       too short to sample) the full MSB-first radix select runs instead: 8-bit digit histograms
+//                       in LDS (lane = channel, so LDS atomics never collide) until the bucket is small, then an
+//                       exact finish.  The same pass leaves the comparison masks of the edge stage.
 //   threshold    :74-75 NF * 10^(SNR/10)
 //   edges        :85-135 the leading/trailing-edge state machine is a 2-state automaton
 //                       next = active ? (mag > thr) : (mag >= thr); each tile of frames is summarised
 //                       as a 2-bit transition function, the functions are scanned per channel, and the
 //                       tiles are replayed with their incoming state to count and emit edge indices.
 //   per pulse    :98-132 one workgroup per pulse: medians of the magnitudes and of the wrapped phase
-//                       steps by the same radix select (values cached in LDS when they fit).
+//                       steps by rank counting or a three-scan bucket select (values cached in LDS when they fit).
 //
-// Arithmetic is float64 like the MATLAB script (the F x M input is promoted sample by sample).
+// The raw-stream script (matlab/create_pdws.m:30-105, pfb_pdw_extract_raw) shares the edge and pulse stages; its
+// one column makes the noise floor a time-parallel radix select whose leading digits are predicted from a small
+// sample and proven by the first counting pass, and its masks a comparison of integer keys.
+//
+// Arithmetic is float64 like the MATLAB scripts: everything that decides an outcome is computed on the exact float64
+// |y|^2 (float32 only screens what cannot matter).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
