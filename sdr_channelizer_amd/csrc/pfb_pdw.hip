@@ -527,6 +527,11 @@ constexpr int kBracketSlots = 16;  // staging slots per (wave, channel): 4 waves
 
 // grid = (column groups of 64, a few workgroups per CU); a workgroup walks row groups of kBracketRows frames
 // (long-lived workgroups read faster than thousands of short ones), flushing its staging columns after each.
+// LPR = lanes per row.  64: lane = channel, column groups of 64 (blockIdx.x).  8 / 16 / 32 for M <= LPR (the small
+// banks: numBands = fs * 1e-6 at 8 ... 32 Msps): a wave-load covers 64 / LPR consecutive rows, lane (sub, channel) owns
+// rows sub, sub + RPW, ... of a 64-row word -- every lane loads, where lane = channel would leave 7 of 8 idle at M = 8 --
+// and the word of a channel is the OR of its RPW lanes' bits.
+template <int LPR>
 __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long long F, int M,
                                                           const unsigned long long* pre_lo, const unsigned long long* pre_hi,
                                                           double gain2, double* cand, unsigned cap, unsigned* cand_n,
@@ -534,11 +539,18 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
                                                           unsigned long long* f0, unsigned long long* f1, long long words,
                                                           unsigned long long* undecided, unsigned* und_n, unsigned* flags,
                                                           int row_groups) {
+  constexpr int RPW = 64 / LPR;                                            // rows per wave-load
+  constexpr int kBatch = kBracketInFlight < LPR ? kBracketInFlight : LPR;  // a lane owns LPR rows of a word
   __shared__ float2 stage[4][kBracketSlots][64];
   __shared__ unsigned char cnt[4][64];
   __shared__ unsigned cand_cnt[64], cand_base[64];
+  __shared__ unsigned long long below_acc[64];  // per channel of this workgroup: "below" counts, sent out once at the end
+  if (threadIdx.x < 64) below_acc[threadIdx.x] = 0ull;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
+  const int sub = lane / LPR;                                              // 0 when LPR == 64
+  const int col = LPR == 64 ? blockIdx.x * 64 + lane : lane % LPR;
+  const int lane_off = sub * M + col;                                      // element offset of this lane inside a wave-load
+  auto chan_of = [&](int c) { return LPR == 64 ? (int)blockIdx.x * 64 + c : c % LPR; };  // channel of staging column c
   const bool valid = col < M;
   constexpr unsigned long long kLow = (1ull << (64 - 8 * kSamplePasses)) - 1ull;
   constexpr int kWordsPerBlock = kBracketRows / 64;
@@ -595,14 +607,14 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
           // whose batch reaches the threshold's lower limit looks at its samples again.  A third fewer vector instructions
           // -- and no faster (905 against 910 us in the same process): the pass is bound by its access shape.
           const float2* rows = y + r0s * M;
-          for (int i = 0; i < 64; i += kBracketInFlight) {  // rows in flight per lane
-            float2 v[kBracketInFlight];
+          for (int i = 0; i < LPR; i += kBatch) {  // the lane's rows r0 + (i + u) RPW + sub, kBatch of them in flight
+            float2 v[kBatch];
 #pragma unroll
-            for (int u = 0; u < kBracketInFlight; ++u) v[u] = (rows + (long long)(i + u) * M)[col];
+            for (int u = 0; u < kBatch; ++u) v[u] = (rows + (long long)((i + u) * RPW) * M)[lane_off];
             unsigned ov = 0u, ub = 0u, sb = 0u;
             float mx = 0.0f;
 #pragma unroll
-            for (int u = 0; u < kBracketInFlight; ++u) {
+            for (int u = 0; u < kBatch; ++u) {
               const float m32 = __fmaf_rn(v[u].x, v[u].x, __fmul_rn(v[u].y, v[u].y));
               const bool is_below = m32 < sA;
               nb32 += (unsigned)is_below;
@@ -615,28 +627,47 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
             }
             if (!(mx < sC)) {
 #pragma unroll
-              for (int u = 0; u < kBracketInFlight; ++u) {
+              for (int u = 0; u < kBatch; ++u) {
                 const float m32 = __fmaf_rn(v[u].x, v[u].x, __fmul_rn(v[u].y, v[u].y));
                 ov |= (unsigned)(m32 > sD) << u;
                 ub |= (unsigned)(!(m32 < sC) && !(m32 > sD)) << u;
               }
             }
-            over |= (unsigned long long)ov << i;
+            if constexpr (RPW == 1) {
+              over |= (unsigned long long)ov << i;
+            } else {
+              while (ov) {  // bit u of the batch is row (i + u) RPW + sub of the word
+                const int u = __ffs((int)ov) - 1;
+                ov &= ov - 1u;
+                over |= 1ull << ((i + u) * RPW + sub);
+              }
+            }
             unsigned bits = ub | sb;
             while (bits) {  // the threshold's zone, a full column: reload (the line is in cache) and classify exactly
               const int u = __ffs((int)bits) - 1;
               bits &= bits - 1u;
-              exact(y[(r0 + i + u) * M + col], i + u, (sb >> u) & 1u, (ub >> u) & 1u);
+              const int row = (i + u) * RPW + sub;
+              exact(y[(r0 + row) * M + col], row, (sb >> u) & 1u, (ub >> u) & 1u);
             }
           }
         } else {
-          for (int i = 0; i < 64; ++i) {
-            if (r0 + i < F) exact(y[(r0 + i) * M + col], i, true, true);
-            else pad |= 1ull << i;
+          for (int t = 0; t < LPR; ++t) {
+            const int row = t * RPW + sub;
+            if (r0 + row < F) exact(y[(r0 + row) * M + col], row, true, true);
+            else pad |= 1ull << row;
           }
         }
-        f0[w * M + col] = over;
-        f1[w * M + col] = over | pad;
+        if constexpr (RPW > 1) {  // a channel's word = its RPW lanes' rows
+#pragma unroll
+          for (int d = LPR; d < 64; d <<= 1) {
+            over |= __shfl_xor(over, d);
+            pad |= __shfl_xor(pad, d);
+          }
+        }
+        if (sub == 0) {
+          f0[w * M + col] = over;
+          f1[w * M + col] = over | pad;
+        }
       }
     }
     nb += nb32;
@@ -655,8 +686,11 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
       is_cand = has && k >= klo && k <= khi;
     };
     for (int c = wave; c < 64; c += 4) {
-      const int gc = blockIdx.x * 64 + c;
-      if (gc >= M) break;
+      const int gc = chan_of(c);
+      if (gc >= M) {  // uniform over the wave
+        if (lane == 0) cand_cnt[c] = 0u;
+        continue;
+      }
       double m;
       unsigned long long k;
       bool is_below, is_cand;
@@ -664,20 +698,29 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
       const unsigned long long vb = __ballot(is_below), vc = __ballot(is_cand);
       if (lane == 0) cand_cnt[c] = (unsigned)__popcll(vc);
       if (vb) {
-        if (lane == __ffsll((long long)vb) - 1) atomicAdd(&below[gc], (unsigned long long)__popcll(vb));
+        if (lane == __ffsll((long long)vb) - 1) atomicAdd(&below_acc[c % LPR], (unsigned long long)__popcll(vb));
         if (is_below) atomicMax(&max_below[gc], k);
       }
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
-      const int gc = blockIdx.x * 64 + threadIdx.x;
-      cand_base[threadIdx.x] = (gc < M && cand_cnt[threadIdx.x]) ? atomicAdd(&cand_n[gc], cand_cnt[threadIdx.x]) : 0u;
+    // one append per CHANNEL and workgroup (64 / LPR staging columns share a channel when rows are packed: with a
+    // returning atomic per column the eight channels of an M = 8 bank took 2 M of them each -- 5.9 ms for 2 GB)
+    if (threadIdx.x < LPR) {
+      const int gc = chan_of((int)threadIdx.x);
+      unsigned tot = 0u;
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) tot += cand_cnt[threadIdx.x + j * LPR];
+      unsigned b0 = (gc < M && tot) ? atomicAdd(&cand_n[gc], tot) : 0u;
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) {
+        cand_base[threadIdx.x + j * LPR] = b0;
+        b0 += cand_cnt[threadIdx.x + j * LPR];
+      }
     }
     __syncthreads();
     for (int c = wave; c < 64; c += 4) {
-      const int gc = blockIdx.x * 64 + c;
-      if (gc >= M) break;
-      if (cand_cnt[c] == 0u) continue;  // uniform over the wave
+      const int gc = chan_of(c);
+      if (gc >= M || cand_cnt[c] == 0u) continue;  // uniform over the wave
       double m;
       unsigned long long k;
       bool is_below, is_cand;
@@ -692,8 +735,13 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
     __syncthreads();  // the staging columns are free again
   }
   if (valid) {
-    if (nb) atomicAdd(&below[col], nb);
+    if (nb) atomicAdd(&below_acc[lane % LPR], nb);
     if (best) atomicMax(&max_below[col], best);
+  }
+  __syncthreads();
+  if (threadIdx.x < LPR) {
+    const int gc = chan_of((int)threadIdx.x);
+    if (gc < M && below_acc[threadIdx.x]) atomicAdd(&below[gc], below_acc[threadIdx.x]);
   }
 }
 
@@ -1906,7 +1954,9 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
       const int row_groups = (int)((words * 64 + kBracketRows - 1) / kBracketRows);
       // many short-lived workgroups (one or two row groups each) beat a few long-lived ones here: 0.83 vs 0.92 ms
       const int gy = std::max(1, std::min(row_groups, 32 * 256 / cgroups));
-      hipLaunchKernelGGL(pdw_bracket_kernel, dim3(cgroups, gy), dim3(256), 0, st, d_y, F, Mi,
+      // small banks: several rows per wave-load (lanes per row = the power of two that holds M)
+      auto kern = Mi > 32 ? pdw_bracket_kernel<64> : Mi > 16 ? pdw_bracket_kernel<32> : Mi > 8 ? pdw_bracket_kernel<16> : pdw_bracket_kernel<8>;
+      hipLaunchKernelGGL(kern, dim3(cgroups, gy), dim3(256), 0, st, d_y, F, Mi,
                          (const unsigned long long*)d_prefix, (const unsigned long long*)d_prefix_hi, gain * gain, d_cand, cap,
                          d_cand_n, d_below, d_maxbelow, e.f0, e.f1, words, d_und, d_und_n, d_flags, row_groups);
     }
