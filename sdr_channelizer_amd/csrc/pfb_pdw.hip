@@ -753,27 +753,92 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
 // the upper one unless that one repeats.  Also checks that the threshold really lies inside the band the
 // provisional masks assumed (flag 8 if not).
 constexpr int kFinishLds = 4096;  // bucket members held in LDS; a larger bucket (heavily tied data) keeps selecting in memory
+
+// The select is split over gridDim.y workgroups per channel (one workgroup scanning a channel's 84 000 candidates twice
+// was 0.12 ms on 128 of the 256 CUs, and 1 ms for the 670 000 candidates of an M = 8 matrix on 8 of them):
+// pdw_finish_hist_kernel -- every part histograms its share of the candidates on the first undecided digit into
+// fin.hist; pdw_bracket_finish_kernel -- every part finds the median's digit in that histogram, moves its share of
+// that digit's bucket into fin.bucket, and the LAST part to arrive (a ticket) holds the bucket in LDS and finishes.
+constexpr int kFinishBits = 11, kFinishBins = 1 << kFinishBits;  // the first digit: wide enough to leave <= kFinishLds members of 4 M candidates
+struct FinishShared {
+  unsigned* hist;               // [M][kFinishBins] first-digit histogram of the candidates
+  unsigned long long* bucket;   // [M][kFinishLds] keys of the median's bucket
+  unsigned* bucket_n;           // [M]
+  unsigned long long* lt_max;   // [M] largest candidate key below the bucket
+  unsigned* ticket;             // [M]
+};
+
+// what every part derives from the channel's counters; false: the bracket did not hold the median (or overflowed)
+struct FinishSetup {
+  unsigned long long n, lo, hi;
+  long long r0;
+  int shared_bits;
+};
+__device__ __forceinline__ bool finish_setup(int col, long long F, unsigned cap, const unsigned* cand_n,
+                                             const unsigned long long* below, const unsigned long long* pre_lo,
+                                             const unsigned long long* pre_hi, FinishSetup& q) {
+  constexpr unsigned long long kLow = (1ull << (64 - 8 * kSamplePasses)) - 1ull;
+  const unsigned long long b = below[col], target = (unsigned long long)(F / 2);
+  q.n = cand_n[col];
+  if (q.n > cap || b > target || target - b >= q.n) return false;
+  q.lo = pre_lo[col] & ~kLow;
+  q.hi = pre_hi[col] | kLow;
+  q.shared_bits = q.lo == q.hi ? 64 : __clzll((long long)(q.lo ^ q.hi));  // leading bits every candidate has
+  q.r0 = (long long)(target - b);  // the upper middle value's rank among the candidates
+  return true;
+}
+
+__global__ void __launch_bounds__(1024) pdw_finish_hist_kernel(long long F, const double* cand, unsigned cap,
+                                                               const unsigned* cand_n, const unsigned long long* below,
+                                                               const unsigned long long* pre_lo,
+                                                               const unsigned long long* pre_hi, FinishShared fin) {
+  __shared__ unsigned hist[kFinishBins];
+  const int col = blockIdx.x;
+  FinishSetup q;
+  if (!finish_setup(col, F, cap, cand_n, below, pre_lo, pre_hi, q) || q.shared_bits == 64) return;  // uniform
+  const int width = 64 - q.shared_bits < kFinishBits ? 64 - q.shared_bits : kFinishBits, shift = 64 - q.shared_bits - width;
+  const unsigned dmask = (1u << width) - 1u;
+  const double* v = cand + (size_t)col * cap;
+  const long long i_begin = (long long)(q.n * blockIdx.y / gridDim.y), i_end = (long long)(q.n * (blockIdx.y + 1) / gridDim.y);
+  for (int i = threadIdx.x; i < kFinishBins; i += blockDim.x) hist[i] = 0u;
+  __syncthreads();
+  for (long long i0 = i_begin; i0 < i_end; i0 += 8ll * blockDim.x) {  // uniform trip count: hist_add uses wave-wide votes
+    unsigned long long kk[8];
+    bool in[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long i = i0 + (long long)u * blockDim.x + threadIdx.x;
+      in[u] = i < i_end;
+      kk[u] = in[u] ? dkey(v[i]) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) hist_add(hist, (unsigned)(kk[u] >> shift) & dmask, in[u]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kFinishBins; i += blockDim.x)
+    if (hist[i]) atomicAdd(&fin.hist[(size_t)col * kFinishBins + i], hist[i]);
+}
+
 __global__ void __launch_bounds__(1024) pdw_bracket_finish_kernel(long long F, const double* cand, unsigned cap,
                                                                   const unsigned* cand_n, const unsigned long long* below,
                                                                   const unsigned long long* max_below,
                                                                   const unsigned long long* pre_lo,
                                                                   const unsigned long long* pre_hi, double gain, double* nf,
-                                                                  unsigned* flags) {
+                                                                  unsigned* flags, FinishShared fin) {
   __shared__ unsigned hist[256];
   __shared__ unsigned long long pick[2];
   __shared__ unsigned long long lt_count, lt_max;
   __shared__ unsigned long long members[kFinishLds];
-  __shared__ unsigned members_n;
-  const int col = blockIdx.x;
-  const unsigned long long n = cand_n[col], b = below[col], target = (unsigned long long)(F / 2);
-  if (n > cap || b > target || target - b >= n) {  // uniform over the workgroup
-    if (threadIdx.x == 0) { atomicOr(flags, 2u); nf[col] = 0.0; }
+  __shared__ unsigned members_n, my_ticket;
+  const int col = blockIdx.x, part = blockIdx.y, parts = gridDim.y;
+  FinishSetup q;
+  if (!finish_setup(col, F, cap, cand_n, below, pre_lo, pre_hi, q)) {  // uniform over the workgroup
+    if (part == 0 && threadIdx.x == 0) { atomicOr(flags, 2u); nf[col] = 0.0; }
     return;
   }
-  constexpr unsigned long long kLow = (1ull << (64 - 8 * kSamplePasses)) - 1ull;
-  const unsigned long long lo = pre_lo[col] & ~kLow, hi = pre_hi[col] | kLow;
-  const int shared_bits = lo == hi ? 64 : __clzll((long long)(lo ^ hi));  // leading bits every candidate has
-  const long long r0 = (long long)(target - b);  // the upper middle value's rank among the candidates
+  const unsigned long long n = q.n, lo = q.lo, hi = q.hi;
+  const int shared_bits = q.shared_bits;
+  const long long r0 = q.r0;
   const double* v = cand + (size_t)col * cap;
   auto getkey = [&](long long i) { return dkey(v[i]); };
   const bool even = (F & 1) == 0;
@@ -781,33 +846,73 @@ __global__ void __launch_bounds__(1024) pdw_bracket_finish_kernel(long long F, c
   unsigned long long k1;
   bool lower_known = false;  // lt_count / lt_max already hold the candidates below k1
   if (shared_bits == 64) {
+    if (part != 0) return;
     k1 = lo;
   } else {
     long long r = r0;
     int db = shared_bits;  // bits decided so far
     unsigned long long pfx = db ? lo & (~0ull << (64 - db)) : 0ull;
-    unsigned bucket = (unsigned)n;
-    // passes over all the candidates until the bucket fits LDS: the 8 bits right below the shared ones spread the
-    // bracket's population over up to 256 buckets, so one pass is the rule
+    unsigned bucket;
+    {  // the first digit (kFinishBits wide): every part reads the histogram all the parts built (pdw_finish_hist_kernel)
+      const int width = 64 - db < kFinishBits ? 64 - db : kFinishBits, shift = 64 - db - width;
+      if (threadIdx.x < 64) {  // wave 0: kFinishBins / 64 bins per lane, a shuffle scan, the owning lane walks its bins
+        constexpr int PER = kFinishBins / 64;
+        const unsigned* hc = fin.hist + (size_t)col * kFinishBins + threadIdx.x * PER;
+        unsigned long long sum = 0ull;
+        for (int j = 0; j < PER; ++j) sum += hc[j];
+        unsigned long long inc = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+          const unsigned long long prev = __shfl_up(inc, d);
+          if ((int)threadIdx.x >= d) inc += prev;
+        }
+        unsigned long long cum = inc - sum;
+        const unsigned long long kk = (unsigned long long)r;
+        if (cum <= kk && kk < inc) {  // exactly one lane
+          int j = 0;
+          for (; j < PER - 1; ++j) {
+            if (kk < cum + hc[j]) break;
+            cum += hc[j];
+          }
+          pick[0] = (unsigned long long)(threadIdx.x * PER + j);
+          pick[1] = cum;
+          lt_count = hc[j];  // (borrowed until the setup below: the bucket's size)
+        }
+      }
+      __syncthreads();
+      pfx |= pick[0] << shift;
+      r -= (long long)pick[1];
+      db += width;
+      bucket = (unsigned)lt_count;
+      __syncthreads();
+      if (threadIdx.x == 0) lt_count = 0ull;
+    }
+    if (bucket > (unsigned)kFinishLds && part != 0) return;  // heavily tied data: part 0 keeps selecting in memory, alone
+    // further passes over all the candidates until the bucket fits LDS (the 8 bits right below the shared ones spread
+    // the bracket's population over up to 256 buckets, so this loop does not run as a rule)
+    const bool alone = bucket > (unsigned)kFinishLds || parts == 1;
     while (db < 64 && bucket > (unsigned)kFinishLds) {  // uniform
       const int width = 64 - db < 8 ? 64 - db : 8;
-      block_digit_pass<16>(getkey, (long long)n, r, hist, pick, db, width, pfx, db == shared_bits);
+      block_digit_pass<16>(getkey, (long long)n, r, hist, pick, db, width, pfx, false);
       bucket = hist[(unsigned)(pfx >> (64 - db)) & ((1u << width) - 1u)];
       __syncthreads();
     }
     if (db == 64) {
       k1 = pfx;
     } else {
-      // move the bucket into LDS (slots claimed per wave), and remember the largest candidate below the bucket
+      // move the bucket out of the candidates: this part's share (everything when it works alone), slots claimed per
+      // wave; remember the largest candidate below the bucket
       const unsigned long long dmask = db == 0 ? 0ull : ~0ull << (64 - db);
       const int lane = threadIdx.x & 63;
+      const long long i_begin = alone ? 0 : (long long)(n * part / parts), i_end = alone ? (long long)n : (long long)(n * (part + 1) / parts);
+      unsigned long long* dst = members;  // LDS first (a returning global atomic per vote would chain memory round trips)
+      unsigned* dst_n = &members_n;
       unsigned long long mx = 0ull;
-      for (long long i0 = 0; i0 < (long long)n; i0 += 8ll * blockDim.x) {  // uniform trip count: wave-wide votes
+      for (long long i0 = i_begin; i0 < i_end; i0 += 8ll * blockDim.x) {  // uniform trip count: wave-wide votes
         unsigned long long kk[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {  // eight candidates in flight per thread
           const long long i = i0 + (long long)u * blockDim.x + threadIdx.x;
-          kk[u] = i < (long long)n ? getkey(i) : ~0ull;  // ~0 is neither a member nor below
+          kk[u] = i < i_end ? getkey(i) : ~0ull;  // ~0 is neither a member nor below
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -818,14 +923,38 @@ __global__ void __launch_bounds__(1024) pdw_bracket_finish_kernel(long long F, c
           if (vote) {
             const int leader = __ffsll((long long)vote) - 1;
             unsigned base = 0u;
-            if (lane == leader) base = atomicAdd(&members_n, (unsigned)__popcll(vote));
+            if (lane == leader) base = atomicAdd(dst_n, (unsigned)__popcll(vote));
             base = (unsigned)__shfl((int)base, leader);
-            if (in) members[base + (unsigned)__popcll(vote & ((1ull << lane) - 1ull))] = k;
+            if (in) dst[base + (unsigned)__popcll(vote & ((1ull << lane) - 1ull))] = k;
           }
         }
       }
       if (mx) atomicMax(&lt_max, mx);
       __syncthreads();
+      if (!alone) {
+        // hand over: this part's members go to the channel's bucket in memory (one slot claim per part), and the last
+        // part to arrive finds every part's members and maxima there
+        if (threadIdx.x == 0) my_ticket = members_n ? atomicAdd(&fin.bucket_n[col], members_n) : 0u;  // (borrowed: the base)
+        __syncthreads();
+        {
+          unsigned long long* gb = fin.bucket + (size_t)col * kFinishLds + my_ticket;
+          for (unsigned i = threadIdx.x; i < members_n; i += blockDim.x) gb[i] = members[i];
+        }
+        __syncthreads();  // (the workgroup's stores have left for L2)
+        if (threadIdx.x == 0) {
+          if (lt_max) atomicMax(&fin.lt_max[col], lt_max);
+          __threadfence();  // one release per workgroup: L2 written back before the ticket is drawn (a fence per
+                            // thread made this kernel 0.43 ms)
+          my_ticket = atomicAdd(&fin.ticket[col], 1u);
+          if (my_ticket == (unsigned)parts - 1u) __threadfence();  // the last part: acquire before it reads the others' members
+        }
+        __syncthreads();
+        if (my_ticket != (unsigned)parts - 1u) return;  // uniform
+        const volatile unsigned long long* src = fin.bucket + (size_t)col * kFinishLds;
+        for (unsigned i = threadIdx.x; i < bucket; i += blockDim.x) members[i] = src[i];
+        if (threadIdx.x == 0) lt_max = *reinterpret_cast<const volatile unsigned long long*>(&fin.lt_max[col]);
+        __syncthreads();
+      }
       const long long r_in = r;  // rank inside the bucket
       bool first = true;
       while (db < 64) {  // the remaining bits, decided among the members
@@ -1886,6 +2015,7 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
   std::vector<double> h_nf(M), h_binf(M);
   unsigned h_flags = 0;
   size_t zero_bytes = 0;
+  FinishShared fin{};
   int passes = 0;
   const double gain = std::pow(10.0, snr_threshold_db / 10.0);  // :74-75 (dB applied to magnitude with /10)
   const int row_blocks = (int)std::min<long long>(1024, std::max<long long>(1, F / 256));
@@ -1898,6 +2028,8 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
     need += padded((size_t)M * 256 * sizeof(unsigned)) + 2 * padded(M * sizeof(unsigned)) + 2 * padded(sizeof(unsigned));
     need += 4 * padded(2 * M * sizeof(unsigned long long)) + padded((size_t)kUndecided * sizeof(unsigned long long));
     need += padded(cand_elems * sizeof(double)) + padded(M * sizeof(double));
+    need += padded((size_t)M * kFinishBins * sizeof(unsigned)) + 3 * padded(M * sizeof(unsigned long long)) +
+            padded((size_t)M * kFinishLds * sizeof(unsigned long long));  // the split candidate select
     if (sampled) need += padded((size_t)M * key_ld * sizeof(unsigned));
     need += edge_stage_bytes(words, ntiles, M);
     PDW_TRY(arena_reserve(ws, need));
@@ -1928,7 +2060,12 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
   d_cand_n = take<unsigned>(ws, (size_t)M);
   d_flags = take<unsigned>(ws, 1);
   d_und_n = take<unsigned>(ws, 1);
-  zero_bytes = (size_t)(reinterpret_cast<char*>(d_und_n + 1) - reinterpret_cast<char*>(d_below));
+  fin.hist = take<unsigned>(ws, (size_t)M * kFinishBins);
+  fin.bucket_n = take<unsigned>(ws, (size_t)M);
+  fin.lt_max = take<unsigned long long>(ws, (size_t)M);
+  fin.ticket = take<unsigned>(ws, (size_t)M);
+  zero_bytes = (size_t)(reinterpret_cast<char*>(fin.ticket + M) - reinterpret_cast<char*>(d_below));
+  fin.bucket = take<unsigned long long>(ws, (size_t)M * kFinishLds);
   d_und = take<unsigned long long>(ws, (size_t)kUndecided);
   d_cand = take<double>(ws, cand_elems);
   d_thr = take<double>(ws, M);
@@ -1960,9 +2097,16 @@ static int pdw_extract_impl(const void* y_in, uint64_t frames, uint32_t M, uint3
                          (const unsigned long long*)d_prefix, (const unsigned long long*)d_prefix_hi, gain * gain, d_cand, cap,
                          d_cand_n, d_below, d_maxbelow, e.f0, e.f1, words, d_und, d_und_n, d_flags, row_groups);
     }
-    hipLaunchKernelGGL(pdw_bracket_finish_kernel, dim3(Mi), dim3(1024), 0, st, F, (const double*)d_cand, cap,
-                       (const unsigned*)d_cand_n, (const unsigned long long*)d_below, (const unsigned long long*)d_maxbelow,
-                       (const unsigned long long*)d_prefix, (const unsigned long long*)d_prefix_hi, gain, e.nf, d_flags);
+    {
+      // parts per channel: enough workgroups to fill the chip, no more than a part's share is worth (>= 8192 candidates)
+      const int parts = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(16, 512 / Mi + 1), (long long)(expect / 8192)));
+      hipLaunchKernelGGL(pdw_finish_hist_kernel, dim3(Mi, parts), dim3(1024), 0, st, F, (const double*)d_cand, cap,
+                         (const unsigned*)d_cand_n, (const unsigned long long*)d_below, (const unsigned long long*)d_prefix,
+                         (const unsigned long long*)d_prefix_hi, fin);
+      hipLaunchKernelGGL(pdw_bracket_finish_kernel, dim3(Mi, parts), dim3(1024), 0, st, F, (const double*)d_cand, cap,
+                         (const unsigned*)d_cand_n, (const unsigned long long*)d_below, (const unsigned long long*)d_maxbelow,
+                         (const unsigned long long*)d_prefix, (const unsigned long long*)d_prefix_hi, gain, e.nf, d_flags, fin);
+    }
     hipLaunchKernelGGL(pdw_thr_kernel, dim3((Mi + 255) / 256), dim3(256), 0, st, (const double*)e.nf, gain, d_thr, Mi);
     hipLaunchKernelGGL(pdw_patch_kernel, dim3(64), dim3(256), 0, st, d_y, Mi, (const double*)d_thr,
                        (const unsigned long long*)d_und, (const unsigned*)d_und_n, e.f0, e.f1);
