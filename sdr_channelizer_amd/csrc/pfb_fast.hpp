@@ -2339,14 +2339,20 @@ hipError_t launch_teams_cm(const KernelParams& p, hipStream_t s) {
 template <class K, int NWV, int L>
 hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s);
 
+template <class K, int NWV>
+constexpr bool kSharedFits = sizeof(float2) * NWV * K::LDS_ELEMS +
+                                 sizeof(typename SampleT<K::FMT>::raw_t) * (NWV + 1) * (K::W - 1) * K::D <= 160 * 1024;
+
+// a tile of NWV waves whose chunk buffers + shared halo do not fit one CU's LDS for this sample format (8-byte samples
+// at M = 128) takes the 4-wave tile; hipErrorNotSupported = not even that: the caller goes on to the plain sliding runs
 template <class K, int NWV, int L>
 hipError_t launch_shared(const KernelParams& p, hipStream_t s) {
-  constexpr size_t kLds = sizeof(float2) * NWV * K::LDS_ELEMS +
-                          sizeof(typename SampleT<K::FMT>::raw_t) * (NWV + 1) * (K::W - 1) * K::D;
-  if constexpr (kLds > 160 * 1024) {
-    return hipErrorInvalidValue;  // does not fit one CU's LDS for this sample format
-  } else {
+  if constexpr (kSharedFits<K, NWV>) {
     return launch_shared_impl<K, NWV, L>(p, s);
+  } else if constexpr (NWV > 4 && kSharedFits<K, 4>) {
+    return launch_shared_impl<K, 4, 64>(p, s);
+  } else {
+    return hipErrorNotSupported;
   }
 }
 
@@ -2501,19 +2507,24 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   if constexpr (K::NT == 64 && K::C == 8 && !K::PINGPONG) {
     if (p.schedule == 3) {  // shared-halo sliding windows: tile_waves runs of frames_per_block frames
       const int key = p.tile_waves * 1000 + p.frames_per_block;
-      if (key == 8024) return launch_shared<K, 8, 24>(p, s);
-      if (key == 8032) return launch_shared<K, 8, 32>(p, s);
-      if (key == 8064) return launch_shared<K, 8, 64>(p, s);
-      if (key == 4064) return launch_shared<K, 4, 64>(p, s);
-      if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64 && K::P == 12) {  // tuning sweep set (cfg2 only, keeps build time sane)
-        switch (key) {
-          case 4032: return launch_shared<K, 4, 32>(p, s);
-          case 8048: return launch_shared<K, 8, 48>(p, s);
-          case 16024: return launch_shared<K, 16, 24>(p, s);
-          default: break;
+      hipError_t r = hipErrorNotSupported;
+      if (key == 8024) r = launch_shared<K, 8, 24>(p, s);
+      else if (key == 8032) r = launch_shared<K, 8, 32>(p, s);
+      else if (key == 8064) r = launch_shared<K, 8, 64>(p, s);
+      else if (key == 4064) r = launch_shared<K, 4, 64>(p, s);
+      else {
+        bool done = false;
+        if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64 && K::P == 12) {  // tuning sweep set (cfg2 only, keeps build time sane)
+          switch (key) {
+            case 4032: r = launch_shared<K, 4, 32>(p, s); done = true; break;
+            case 8048: r = launch_shared<K, 8, 48>(p, s); done = true; break;
+            case 16024: r = launch_shared<K, 16, 24>(p, s); done = true; break;
+            default: break;
+          }
         }
+        if (!done) r = launch_shared<K, 8, 24>(p, s);  // any other shape: the tuned default
       }
-      return launch_shared<K, 8, 24>(p, s);  // any other shape: the tuned default
+      if (r != hipErrorNotSupported) return r;  // (no tile fits this sample format: the plain sliding runs below)
     }
   }
   if constexpr (K::NT == 64 && K::M == 64 && K::FMT == PFB_FMT_INT16_IQ && K::C == 8 && K::P == 12) {  // access-shape study schedules (cfg2 only)
