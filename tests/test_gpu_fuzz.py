@@ -36,7 +36,7 @@ def make_input(rng, n, fmt):
     return synth.pulsed_iq_numpy(n, bw, np.int8 if fmt == "int8" else np.int16, seed=int(rng.integers(1 << 30))), bw
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("PFB_FUZZ_CASES", "48"))))  # more with PFB_FUZZ_CASES=N
+@pytest.mark.parametrize("case", range(int(os.environ.get("PFB_FUZZ_CASES", "260"))))  # 20 per shape; more with PFB_FUZZ_CASES=N
 def test_fused_kernels_agree_with_the_generic_kernel(case):
     rng = np.random.default_rng(1000 + case)
     M, P, D, fmts, scheds = SHAPES[case % len(SHAPES)]
