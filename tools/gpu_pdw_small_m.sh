@@ -1,7 +1,7 @@
 #!/bin/bash
 out=gpurun_out/${1:-sm}; mkdir -p $out
 root=$(pwd); export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof -- python3 $root/tools/pdw_small_m.py 8 32 64 > $root/$out/wall.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof -- python3 $root/tools/pdw_small_m.py 8 16 32 56 64 > $root/$out/wall.txt 2>&1
 cd $root
 grep "M=" $out/wall.txt
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1)
