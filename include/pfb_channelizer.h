@@ -186,7 +186,11 @@ typedef struct pfb_shard_config {
   uint32_t struct_size;          /* = sizeof(pfb_shard_config)                                    */
   int32_t rank, world;           /* this handle owns segment `rank` of `world`                    */
   uint32_t ring;                 /* 1: rank 0 receives from rank world-1 (the segments of call i+1 */
-                                 /* follow those of call i: an endless stream, what bench.py times); */
+                                 /* follow those of call i: an endless stream, what bench.py times).  */
+                                 /* The last rank then sends its CARRIED state -- the tail of its    */
+                                 /* previous segment, zeros after pfb_reset -- not the tail of the   */
+                                 /* segment in hand: its send of call i is what rank 0's receive of  */
+                                 /* call i is matched with, and rank 0 is one call ahead of it.      */
                                  /* 0: rank 0 continues from the handle's own state                */
   pfb_halo_exchange_fn exchange; /* may be NULL when world == 1                                   */
   void* user;

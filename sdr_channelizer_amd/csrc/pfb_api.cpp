@@ -1032,7 +1032,15 @@ int pfb_process_shard_async(pfb_handle* h, const void* d_seg, uint64_t n, void* 
     // the segment, the previous call's head frames that still read the landing zone) has finished
     HIP_TRY(hipEventRecord(h->ev_seg, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->s_halo, h->ev_seg, 0));
-    const char* tail = static_cast<const char*>(d_seg) + (size_t)n * h->bps - halo_bytes;
+    // What I pass on: the tail of THIS segment -- except the last rank of a ring, whose successor (rank 0) works on the
+    // NEXT call's first segment: it gets the tail of my PREVIOUS segment, i.e. my carried state (zeros after a reset, so
+    // the very first segment of the stream starts from zero state like a fresh dsp.Channelizer).  A matched transport
+    // pairs rank 0's receive in call i with my send in call i; sending the current tail there would hand rank 0 samples
+    // from its own future.
+    const bool pass_state = h->shard_ring && rank == world - 1;
+    const char* tail = pass_state
+                           ? static_cast<const char*>(h->d_hist[h->cur]) + ((size_t)h->hist_samples * h->bps - halo_bytes)
+                           : static_cast<const char*>(d_seg) + (size_t)n * h->bps - halo_bytes;
     const int crc = h->shard_exchange(h->shard_user, sending ? tail : nullptr, receiving ? pfb_halo_recv_buffer(h) : nullptr,
                                       halo_bytes, sending ? (rank + 1) % world : -1,
                                       receiving ? (rank + world - 1) % world : -1, h->s_halo);
@@ -1129,7 +1137,7 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_nontemporal = value ? 1 : 0;
       return PFB_OK;
     case PFB_OPT_SCHEDULE:
-      if (value < -1 || value > 11) return PFB_ERR_BAD_ARG;
+      if (value < -1 || value > 13 || value == 12) return PFB_ERR_BAD_ARG;
       h->opt_schedule = (int)value;
       return PFB_OK;
     case PFB_OPT_TILE_WAVES:

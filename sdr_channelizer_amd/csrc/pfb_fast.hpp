@@ -270,8 +270,9 @@ template <int N> struct Dft {
 // Kernel configuration
 
 template <int M_, int P_, int D_, int CPT_, int FMT_, int C_, int NP_, int R0_, int R1_, int R2_, int RS0_,
-          int RS1_, int RS2_, int FS_, bool PINGPONG_, int MIN_WAVES_, bool TW_TABLE_ = false>
+          int RS1_, int RS2_, int FS_, bool PINGPONG_, int MIN_WAVES_, bool TW_TABLE_ = false, bool WAVE_FRAMES_ = false>
 struct FastCfg {
+  static constexpr bool WAVE_FRAMES = WAVE_FRAMES_;  // schedule W only: every wave transforms whole frames by itself
   static constexpr int M = M_, P = P_, D = D_, CPT = CPT_, FMT = FMT_, C = C_, NP = NP_;
   static constexpr int LANES = D / CPT;                  // threads that own columns
   static constexpr int NT = (LANES + 63) / 64 * 64;      // threads per workgroup (whole waves)
@@ -300,7 +301,7 @@ struct FastCfg {
   static_assert(R(0) * RS(0) <= FS && R(1) * RS(1) <= FS && (NP < 3 || R(2) * RS(2) <= FS), "frame fits");
   // in-place non-final passes need every read of the pass to precede every write: one iteration per
   // thread, and (multi-wave teams) a barrier between the reads and the writes
-  static_assert(PINGPONG || (C * (M / R(0)) <= NT && (NP < 3 || C * (M / R(1)) <= NT)),
+  static_assert(PINGPONG || WAVE_FRAMES || (C * (M / R(0)) <= NT && (NP < 3 || C * (M / R(1)) <= NT)),
                 "multi-iteration non-final passes need ping-pong buffers");
 };
 
@@ -493,7 +494,11 @@ struct FastKernel {
     }
   }
 
-  template <int I, bool PDW = false>
+  // FULL: every frame of the chunk exists (an interior run): the stores are unconditional, so that the number of
+  // vector-memory operations per step is the same on every path -- the compiler's s_waitcnt counts stay exact across
+  // the chunk loop (a conditional store makes it assume the fewest, i.e. wait for MORE than the load it needs)
+  // MAGSEL: -1 = PFB_FLAG_MAGNITUDE is tested here, 0 / 1 = the caller has (outside its chunk loop: same reason as FULL)
+  template <int I, bool PDW = false, bool FULL = false, int MAGSEL = -1>
   PFB_DEV void pass(const KernelParams& p, float2* src, float2* dst, int tid, long long f0,
                     const v2f (&tw)[2][16], float2* out_base = nullptr, long long frames_lim = -1, PdwLane* pl = nullptr,
                     const float4* thr = nullptr, long long f_run = 0) {
@@ -579,7 +584,7 @@ struct FastKernel {
           }
         }
         const long long f = f0 + fc;
-        if (active && f < p_frames) {
+        if (active && (FULL || f < p_frames)) {
           const bool flip_odd = (OS == 2) && (p.flags & PFB_FLAG_DEROTATE) && ((p.frame0 + f) & 1);
           // derotation of the 2x oversampled bank = a sign on the odd channels of odd frames.  As ONE multiply by a
           // per-lane +-1 (exact, -0 included); `if (flip) v = -v` per store compiled to a negate, a nop and four
@@ -630,7 +635,7 @@ struct FastKernel {
               ptr += step;
               if (col >= M) { col -= M; ptr -= wrap; }
             }
-          } else if (p.flags & PFB_FLAG_MAGNITUDE) {  // fused abs(): 4 bytes per channel instead of 8
+          } else if (MAGSEL == 1 || (MAGSEL < 0 && (p.flags & PFB_FLAG_MAGNITUDE))) {  // fused abs(): 4 bytes per channel instead of 8
             float* rowm = reinterpret_cast<float*>(p_out) + f0 * M + fc * M;
 #pragma unroll
             for (int k = 0; k < R; ++k) *slot(rowm, k) = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
@@ -1130,7 +1135,7 @@ struct FastKernel {
   // tiles of TF frames (global memory, rewritten every other tile, so it lives in L2 / the memory-side cache) instead of
   // `out`; the FFT team moves finished tiles into place transposed, a slice per chunk step (flush_unit below).  The FIR
   // team's only extra duty: at a tile's last chunk its stores must have LEFT before the step's barrier.
-  template <bool INTERIOR, int TF = 0>
+  template <bool INTERIOR, int TF = 0, int MAGSEL = -1>
   PFB_DEV void fir_team(const KernelParams& p, const Consts& k, float2* bufs, long long f_begin, int nch,
                         float2* sc = nullptr, int tile_base = 0) {
     const int tid = threadIdx.x;
@@ -1143,7 +1148,13 @@ struct FastKernel {
         pass<K::NP - 1>(p, buf, nullptr, tid, (long long)(c % CPTL) * C, k.tw, tile, TF);
         if (c % CPTL == CPTL - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile is complete: visible behind the next barrier
       } else {
-        pass<K::NP - 1>(p, buf, nullptr, tid, f_begin + (long long)c * C, k.tw);
+        // the thread index is laundered so that everything the pass derives from it (LDS and store addresses) is
+        // recomputed here -- a few VALU instructions -- instead of being hoisted out of the chunk loop: hoisted, ONE of
+        // them was spilled, and its reload (a vector-memory load, which returns in order) made every step wait for the
+        // row prefetch issued just before it: s_waitcnt vmcnt(0) four times per iteration of the steady-state loop
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        pass<K::NP - 1, false, INTERIOR, MAGSEL>(p, buf, nullptr, t2, f_begin + (long long)c * C, k.tw);
       }
     };
     const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
@@ -1161,37 +1172,47 @@ struct FastKernel {
 #pragma unroll
       for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + u * C + t, W - 1 + u * C + t, c0, raw[u][t]);
     int b_fir = 0, b_last = 1;  // buffer of chunk ci, buffer of chunk ci - 2 (= (ci + 1) % 3)
-    for (int ci2 = 0; ci2 < nch; ci2 += 2) {
+    // One chunk step.  U: which of the two row sets holds chunk ci; LASTP: chunk ci - 2 exists (every step but a run's
+    // first two, which are peeled off so that the steady-state loop issues the same stores on every path: see pass<FULL>).
+    // (An unconditional, clamped prefetch would make the loads path-independent too, but its 64-bit row addresses cost
+    // this team the registers it does not have: 8-12 spilled, reloaded inside the loop.)
+    auto step = [&]<int U, bool LASTP>(int ci) {
+      const long long f0 = f_begin + (long long)ci * C;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int ci = ci2 + u;
-        const long long f0 = f_begin + (long long)ci * C;
+      for (int t = 0; t < C; ++t)
 #pragma unroll
-        for (int t = 0; t < C; ++t)
+        for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[U][t][cc]);
+      if (ci + 2 < nch) {
+        const long long rel = (long long)(ci + 2) * C + (W - 1);
 #pragma unroll
-          for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[u][t][cc]);
-        if (ci + 2 < nch) {
-          const long long rel = (long long)(ci + 2) * C + (W - 1);
-#pragma unroll
-          for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f0 + 2 * C + t, rel + t, c0, raw[u][t]);
-        }
-        // (TF > 0: the stores first, so that at a tile's end they have the FIR's time to leave before the wait for them)
-        if constexpr (TF > 0) { if (ci >= 2) pass<K::NP - 1>(p, bufs + b_last * K::BUF, nullptr, tid, (long long)((ci - 2) % CPTL) * C, k.tw,
-                                                              sc + (size_t)((tile_base + (ci - 2) / CPTL) & 1) * TF * M, TF); }
-        fir_to_lds(k, x, bufs + b_fir * K::BUF, tid);
-#pragma unroll
-        for (int i = 0; i < W - 1; ++i)
-#pragma unroll
-          for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
-        if constexpr (TF > 0) {
-          if (ci >= 2 && (ci - 2) % CPTL == CPTL - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile is complete: visible behind the barrier
-        } else {
-          if (ci >= 2) last_pass(bufs + b_last * K::BUF, ci - 2);
-        }
-        __syncthreads();  // (barrier ci) chunk ci handed to the FFT team, buffer of chunk ci - 2 free again
-        b_fir = (b_fir == 2) ? 0 : b_fir + 1;
-        b_last = (b_last == 2) ? 0 : b_last + 1;
+        for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f0 + 2 * C + t, rel + t, c0, raw[U][t]);
       }
+      // (TF > 0: the stores first, so that at a tile's end they have the FIR's time to leave before the wait for them)
+      if constexpr (TF > 0 && LASTP) {
+        pass<K::NP - 1>(p, bufs + b_last * K::BUF, nullptr, tid, (long long)((ci - 2) % CPTL) * C, k.tw,
+                        sc + (size_t)((tile_base + (ci - 2) / CPTL) & 1) * TF * M, TF);
+      }
+      fir_to_lds(k, x, bufs + b_fir * K::BUF, tid);
+#pragma unroll
+      for (int i = 0; i < W - 1; ++i)
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
+      if constexpr (LASTP) {
+        if constexpr (TF > 0) {
+          if ((ci - 2) % CPTL == CPTL - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile is complete: visible behind the barrier
+        } else {
+          last_pass(bufs + b_last * K::BUF, ci - 2);
+        }
+      }
+      __syncthreads();  // (barrier ci) chunk ci handed to the FFT team, buffer of chunk ci - 2 free again
+      b_fir = (b_fir == 2) ? 0 : b_fir + 1;
+      b_last = (b_last == 2) ? 0 : b_last + 1;
+    };
+    step.template operator()<0, false>(0);
+    step.template operator()<1, false>(1);
+    for (int ci2 = 2; ci2 < nch; ci2 += 2) {
+      step.template operator()<0, true>(ci2);
+      step.template operator()<1, true>(ci2 + 1);
     }
     // drain: the FFT team finishes chunk nch - 1 while chunk nch - 2 gets its last pass, then chunk nch - 1
     if (nch >= 2) last_pass(bufs + b_last * K::BUF, nch - 2);
@@ -1261,7 +1282,7 @@ struct FastKernel {
     team_sync<true>();  // the next unit overwrites the LDS tile
   }
 
-  template <int TF = 0>
+  template <int TF = 0, int MAGSEL = -1>
   PFB_DEV void run_teams(const KernelParams& p, float2* bufs, float2* tiles = nullptr) {
     static_assert(K::NP == 3 && !K::PINGPONG && NT % 64 == 0, "three in-place passes");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1320,8 +1341,8 @@ struct FastKernel {
       if (f_begin >= p.frames) break;
       if (wave < NT / 64) {
         const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_begin + p.frames_per_block <= p.frames);
-        if (interior) fir_team<true, TF>(p, k, bufs, f_begin, nch, sc, tile_base);
-        else fir_team<false, TF>(p, k, bufs, f_begin, nch, sc, tile_base);
+        if (interior) fir_team<true, TF, MAGSEL>(p, k, bufs, f_begin, nch, sc, tile_base);
+        else fir_team<false, TF, MAGSEL>(p, k, bufs, f_begin, nch, sc, tile_base);
       } else {
         // (s_setprio for either team, measured: cfg4 -3 % / 0, M=560 +1.6 % / +1 %: noise)
         int b = 0;          // buffer of chunk s - 1
@@ -1356,6 +1377,392 @@ struct FastKernel {
     if constexpr (TF > 0) {
       if (wave >= NT / 64) while (pend > 0) { flush_begin(); flush_end(); }  // the last tile of the last run: nobody to keep step with
     }
+  }
+
+  // ---- schedule W: several independent workgroups per CU (large M) --------------------------------------------
+  // The team kernel (schedule T) holds its sliding window as converted float pairs: 168 registers per FIR thread,
+  // three 34 KB chunk buffers, so ONE 12-wave workgroup per CU whose teams meet at a barrier every 4 frames; nothing
+  // hides a run's start-up (W-1 halo rows, two steps of fill, two of drain), so runs must be long (512 frames = 2 MB
+  // of input per CU), and 256 CUs each streaming their own megabytes is the access shape HBM serves worst (DESIGN.md
+  // section 6).  Here a workgroup is NT/64 waves, every wave does both jobs, and the state between chunks is small
+  // enough for TWO (M = 1024) or more workgroups per CU, which are not synchronised with each other: while one
+  // filters (VALU) the other transforms and stores (LDS, memory), and one's start-up is covered by the other's
+  // steady state, so runs can be short.
+  //  * the window is kept as the RAW samples (one register per int16 / int8 pair instead of two) and converted when
+  //    used: W-1+C conversions per column and chunk instead of C, i.e. +12 % VALU work in the FIR at M = 1024 for
+  //    30 instead of 60 persistent registers;
+  //  * a chunk is C = NT/64 frames in ONE buffer: FIR by everybody -> barrier -> wave w runs ALL passes of frame w
+  //    by itself (M/64 points per lane: wave-local, no barrier inside the FFT) and stores it -> barrier;
+  //  * a thread's two adjacent columns are two adjacent branch outputs: one ds_write_b128 (the team kernel's
+  //    ds_write_b64 pairs were a 2-way bank conflict, 15 % of its LDS cycles).
+  // Same taps, same accumulation order (taps ascending), same passes: bit-identical to the other plans of the shape.
+  template <bool MAG>
+  PFB_DEV void last_pass_frame(const KernelParams& p, const float2* fbuf, int lane, long long f) {
+    constexpr int I = K::NP - 1, R = K::R(I), KK = K::K(I), RS = K::RS(I);
+    constexpr int IPF = M / R, ITERS = (IPF + 63) / 64;
+    static_assert(K::S(I) == 1 && !CM && OS == 1, "frame-major, critically sampled");
+    v2f x[ITERS][R];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int item = lane + it * 64;
+      const v2f* s2 = reinterpret_cast<const v2f*>(fbuf) + ((IPF % 64 == 0) || item < IPF ? item : 0);
+#pragma unroll
+      for (int n = 0; n < R; ++n) x[it][n] = s2[n * RS];
+    }
+    const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int kk = lane + it * 64;
+      Dft<R>::run(x[it]);
+      if ((IPF % 64 == 0) || kk < IPF) {
+        auto col_of = [&](int ch) {
+          const int c2 = ch + shift;
+          return c2 >= M ? c2 - M : c2;
+        };
+        // (a wave-uniform row pointer + an UNSIGNED 32-bit lane offset: the address form that needs no 64-bit vector
+        // arithmetic and no register pair per pointer)
+        auto slot = [&](auto* rowp, int k) {
+          if constexpr (K::POW2) {  // fftshift swaps the row's halves: two base pointers, compile-time offsets (see pass<>)
+            auto* lo = rowp + (unsigned)(kk + shift);
+            auto* hi = rowp + (unsigned)(kk + (M / 2 - shift));
+            return (k < R / 2) ? lo + k * KK : hi + (k - R / 2) * KK;
+          } else {
+            return rowp + (unsigned)col_of(kk + k * KK);
+          }
+        };
+        if constexpr (MAG) {
+          float* rowm = reinterpret_cast<float*>(p.out) + f * M;
+#pragma unroll
+          for (int k = 0; k < R; ++k) *slot(rowm, k) = sqrtf(x[it][k].x * x[it][k].x + x[it][k].y * x[it][k].y);
+        } else {
+          float2* row = p.out + f * M;
+#pragma unroll
+          for (int k = 0; k < R; ++k) *reinterpret_cast<v2f*>(slot(row, k)) = x[it][k];
+        }
+      }
+    }
+  }
+
+  // taps of column pair `pr` of this thread (columns c0 + 2 pr, c0 + 2 pr + 1), two taps per register pair: the table of setup()
+  PFB_DEV void load_taps_pair(const KernelParams& p, int tid, int pr, v2f (&hp)[(W + 1) / 2][2]) {
+    const int c0 = tid * CPT + 2 * pr;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int col = (K::LANES < NT && c0 >= D) ? 0 : c0 + cc;  // idle lanes read column 0's taps
+      const float4* tl = reinterpret_cast<const float4*>(p.taps_lane + (size_t)col * K::WP);
+#pragma unroll
+      for (int q4 = 0; q4 < K::WP / 4; ++q4) {
+        const float4 v = tl[q4];
+        if (2 * q4 < (W + 1) / 2) hp[2 * q4][cc] = (v2f){v.x, v.y};
+        if (2 * q4 + 1 < (W + 1) / 2) hp[2 * q4 + 1][cc] = (v2f){v.z, v.w};
+      }
+    }
+  }
+
+  // Twiddle rows of the non-final passes as this kernel keeps them in LDS: in registers they are 2 R per pass, and from
+  // the global table their loads would queue behind the row prefetch (a wave's vector-memory operations return in order:
+  // a pass that waits for a twiddle load waits for every HBM load issued before it).  Row stride: even (16-byte reads)
+  // with an odd half, so that the sixteen lanes of a ds_read_b128 group read sixteen different bank quads.
+  static constexpr int TWS(int i) { return (K::R(i) / 2) % 2 ? K::R(i) : K::R(i) + 2; }
+  static constexpr int TWL_OFF(int i) { int o = 0; for (int j = 0; j < i; ++j) o += K::S(j) * TWS(j); return o; }
+  static constexpr int TWL_ELEMS = TWL_OFF(K::NP - 1);
+
+  PFB_DEV void fill_twiddles(const KernelParams& p, float2* twl) {
+#pragma unroll
+    for (int i = 0; i < K::NP - 1; ++i) {
+      const int R = K::R(i), n = K::S(i) * R;
+      for (int idx = threadIdx.x; idx < n; idx += NT) twl[TWL_OFF(i) + (idx / R) * TWS(i) + idx % R] = p.tw_lane[K::TW_OFF(i) + idx];
+    }
+  }
+
+  // One non-final pass of one frame by one wave, in place, like pass_frame, twiddles from the LDS table.
+  template <int I>
+  PFB_DEV void pass_frame_lean(float2* fbuf, const float2* twl, int lane) {
+    constexpr int R = K::R(I), S = K::S(I), KK = K::K(I), RS = K::RS(I);
+    constexpr int IPF = M / R;
+    constexpr int S1 = K::S(I + 1), RS1 = K::RS(I + 1);
+    static_assert(I < K::NP - 1 && IPF <= 64 && R % 2 == 0, "one item per lane");
+    const bool active = (IPF == 64) || (lane < IPF);
+    const int item = active ? lane : 0;
+    const int kk = item / S, rest = item % S;
+    v2f x[R];
+    const v2f* s2 = reinterpret_cast<const v2f*>(fbuf) + item;
+#pragma unroll
+    for (int n = 0; n < R; ++n) x[n] = s2[n * RS];
+    const float4* t4 = reinterpret_cast<const float4*>(twl + TWL_OFF(I) + rest * TWS(I));
+    const int n1 = rest / S1, rest2 = rest % S1;
+    v2f* d2 = reinterpret_cast<v2f*>(fbuf) + n1 * RS1 + kk * S1 + rest2;
+    Dft<R>::run(x);
+#pragma unroll
+    for (int k2 = 0; k2 < R / 2; ++k2) {
+      const float4 t = t4[k2];
+      if (k2 > 0) x[2 * k2] = cmul_w(x[2 * k2], (v2f){t.x, t.y});
+      x[2 * k2 + 1] = cmul_w(x[2 * k2 + 1], (v2f){t.z, t.w});
+      if (active) {
+        d2[(2 * k2) * KK * S1] = x[2 * k2];
+        d2[(2 * k2 + 1) * KK * S1] = x[2 * k2 + 1];
+      }
+    }
+  }
+
+  // CPT raw samples of row `rel` of an interior run: uniform 64-bit base in SGPRs + a 32-bit lane offset (the address
+  // form that costs one register per lane; as pointer arithmetic the compiler kept a 64-bit address pair per row)
+  PFB_DEV void load_row_sbase(const raw_t* run_ptr, long long rel, int c0, raw_t (&raw)[CPT]) {
+    static_assert(sizeof(RawVec) % 4 == 0, "whole dwords per lane");
+    typedef unsigned dwords_t __attribute__((ext_vector_type(sizeof(RawVec) / 4)));
+    const int cs = (K::LANES < NT && c0 >= D) ? 0 : c0;  // lanes beyond the last column read column 0 (and never use it)
+    const raw_t* rowp = run_ptr + rel * D;               // wave-uniform
+    const dwords_t v = *reinterpret_cast<const dwords_t*>(rowp + (unsigned)cs);
+    __builtin_memcpy(&raw[0], &v, sizeof(RawVec));
+  }
+
+  // The fast path: whole chunks of a run whose every row (halo included) lies inside `in`, aligned vectors.
+  // The chunk loop is laid out so that the compiler's s_waitcnt counts are EXACT: a wave's vector-memory operations
+  // return in order, the compiler counts them per path, and wherever the count differs between paths into a point it
+  // assumes the fewest younger operations, i.e. waits for more than the load it needs -- typically for every store
+  // issued since.  So (1) the loop is rotated: an iteration is [transform + store chunk i, its first step requesting
+  // the rows of chunk i + 1] then [FIR of chunk i + 1], which keeps a load and its wait in the SAME iteration;
+  // (2) nothing in the loop is conditionally issued: the prefetch past the run's end re-reads the last row, partial
+  // chunks are left to the careful path, PFB_FLAG_MAGNITUDE is a template parameter of the kernel.
+  static constexpr int NWV = NT / 64;        // waves per workgroup
+  static constexpr int FPW = C / (NT / 64);  // frames each wave transforms per chunk
+  static constexpr bool kTapsResident = K::MIN_WAVES <= 2;  // 256 registers: the taps stay; otherwise they are re-read per chunk
+  static constexpr bool kLean = K::MIN_WAVES >= 4;          // 128 registers
+  // r_first, G, r_hi: this workgroup's runs r_first, r_first + G, ... below r_hi (all of them whole, with their halo
+  // inside `in`), chained without a bubble: the step that would request the next chunk's rows requests the next run's
+  // W-1 halo rows as well (into the window registers, which are dead at that point).  G = the grid: with one workgroup
+  // per run there is no second run; with a grid of resident workgroups (PFB_OPT_GRID) the taps, the twiddle table and
+  // the start-up latency are paid once per workgroup, and SHORT runs become affordable -- at any moment the chip then
+  // works on G consecutive short runs, a dense window sweeping through the stream (what HBM
+  // delivers depends on how compact the set of concurrently touched DRAM rows is).
+  template <bool MAG>
+  PFB_DEV void twin_fast(const KernelParams& p, float2* lds, const float2* twl, long long r_first, long long G, long long r_hi) {
+    static_assert(C % NWV == 0 && OS == 1 && K::NP == 3 && !K::PINGPONG, "whole frames per wave and chunk");
+    static_assert(CPT % 2 == 0 && K::S(0) % 2 == 0 && K::RS(0) % 2 == 0 && K::FS % 2 == 0 && D % 2 == 0, "adjacent, aligned branch pairs");
+    constexpr int NPR = CPT / 2;  // column pairs per thread
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: frame indices and row pointers stay scalar
+    const int c0 = (K::LANES < NT && tid >= K::LANES) ? 0 : tid * CPT;  // idle lanes (D not a multiple of 64 CPT) shadow thread 0
+    const bool lane_on = !(K::LANES < NT) || tid < K::LANES;
+    // Registers decide this kernel (workgroups per CU = 512 / registers / waves per workgroup).  Where they do not fit,
+    // the taps (W per column) are NOT kept across the FFT: a column pair's come back from the L2-resident table every
+    // chunk -- the first pair's loads are issued before the last pass, so that they land under its stores and the
+    // barrier, the next pair's under the FIR of the pair before.
+    constexpr int NHP = kTapsResident ? NPR : (NPR > 1 ? 2 : 1);
+    v2f hp[NHP][(W + 1) / 2][2];
+    const v2f conj_mul = (v2f){1.f, (p.flags & PFB_FLAG_CONJUGATE_INPUT) ? -1.f : 1.f};
+    int upos[NPR];  // LDS position of the lower of a pair's two adjacent branch outputs
+#pragma unroll
+    for (int pr = 0; pr < NPR; ++pr) {
+      const int n = D - 1 - (c0 + 2 * pr + 1);
+      upos[pr] = (n / K::S(0)) * K::RS(0) + (n % K::S(0));
+    }
+    if constexpr (kTapsResident) {
+#pragma unroll
+      for (int pr = 0; pr < NPR; ++pr) load_taps_pair(p, tid, pr, hp[pr]);
+    } else {
+      load_taps_pair(p, tid, 0, hp[0]);
+    }
+    const int nch = p.frames_per_block / C;  // chunks per run
+    long long r = r_first;
+    const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((r * p.frames_per_block - (W - 1)) * D + p.base);
+    raw_t win[W - 1][CPT];  // rows f0-(W-1) ... f0-1, as loaded
+    raw_t raw[C][CPT];      // rows f0 ... f0+C-1
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) load_row_sbase(run_ptr, i, c0, win[i]);
+#pragma unroll
+    for (int t = 0; t < C; ++t) load_row_sbase(run_ptr, W - 1 + t, c0, raw[t]);
+    // FIR of a chunk's C frames for my CPT columns, a column pair at a time, then the window slides.  Row i of the NW
+    // window rows feeds frame t with tap j = W-1+t-i; rows are walked newest first so that every accumulator takes its
+    // taps in ascending order (the order of fir_to_lds: bit-identical sums).
+    auto fir_chunk = [&]() {
+#pragma unroll
+      for (int pr = 0; pr < NPR; ++pr) {
+        const int hb = kTapsResident ? pr : (pr & 1);
+        if constexpr (!kTapsResident) { if (pr + 1 < NPR) load_taps_pair(p, tid, pr + 1, hp[(pr + 1) & 1]); }
+        v2f acc[2][C];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+          for (int t = 0; t < C; ++t) acc[cc][t] = (v2f){0.f, 0.f};
+          int tok = 0;
+#pragma unroll
+          for (int i = NW - 1; i >= 0; --i) {
+            const v2f xi = cvt(i >= W - 1 ? raw[i - (W - 1)][2 * pr + cc] : win[i][2 * pr + cc]);
+#pragma unroll
+            for (int t = 0; t < C; ++t) {
+              const int j = W - 1 + t - i;
+              if (j >= 0 && j < W) {
+                if (j & 1) fma_tap_hi(acc[cc][t], xi, hp[hb][j >> 1][cc], tok);
+                else fma_tap_lo(acc[cc][t], xi, hp[hb][j >> 1][cc], tok);
+              }
+            }
+          }
+          if constexpr (kLean) {
+            // (128 registers: a column's C sums leave before the next column starts -- 8-byte writes, a 2-way bank
+            // conflict on C writes per column, instead of holding both columns' sums for the 16-byte write)
+            if (lane_on) {
+              v2f* d2 = reinterpret_cast<v2f*>(lds) + upos[pr] + (1 - cc);
+#pragma unroll
+              for (int t = 0; t < C; ++t) d2[t * K::FS] = acc[cc][t] * conj_mul;
+            }
+            asm volatile("" ::: "memory");
+          }
+        }
+        if constexpr (!kLean) {
+          if (lane_on) {
+            // column c + 1 is branch n - 1 (even), column c branch n: adjacent positions, 16-byte aligned -> one ds_write_b128
+            float4* d4 = reinterpret_cast<float4*>(lds + upos[pr]);
+#pragma unroll
+            for (int t = 0; t < C; ++t) {
+              const v2f a = acc[1][t] * conj_mul, b = acc[0][t] * conj_mul;
+              d4[t * (K::FS / 2)] = make_float4(a.x, a.y, b.x, b.y);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < W - 1; ++i)
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) win[i][cc] = (i + C >= W - 1) ? raw[i + C - (W - 1)][cc] : win[i + C][cc];
+    };
+    fir_chunk();
+    int ci = 0;
+    for (;;) {
+      const long long f0 = r * p.frames_per_block + (long long)ci * C;
+      bool more = true;
+      __syncthreads();  // the chunk is in LDS
+      // my frames of the chunk: wave + NWV fi.  What the next chunk needs is requested between the passes (no
+      // vector-memory load inside them: a pass waiting for a table entry would wait for every row requested before it):
+      // its rows behind the first pass 0 -- they land under the rest of the transform and its stores --, its first
+      // taps behind the last pass 1
+#pragma unroll
+      for (int fi = 0; fi < FPW; ++fi) {
+        const int fc = wave + NWV * fi;
+        float2* fbuf = lds + fc * K::FS;
+        pass_frame_lean<0>(fbuf, twl, lane);
+        if (fi == 0) {
+          asm volatile("" ::: "memory");
+          if (ci + 1 < nch) {  // the run's next chunk
+            ++ci;
+            const long long rel = (long long)ci * C + (W - 1);
+#pragma unroll
+            for (int t = 0; t < C; ++t) load_row_sbase(run_ptr, rel + t, c0, raw[t]);
+          } else if (r + G < r_hi) {  // my next run: its halo (the window registers are dead here) and its first chunk
+            r += G;
+            ci = 0;
+            run_ptr = static_cast<const raw_t*>(p.in) + ((r * p.frames_per_block - (W - 1)) * D + p.base);
+#pragma unroll
+            for (int i = 0; i < W - 1; ++i) load_row_sbase(run_ptr, i, c0, win[i]);
+#pragma unroll
+            for (int t = 0; t < C; ++t) load_row_sbase(run_ptr, W - 1 + t, c0, raw[t]);
+          } else {
+            more = false;
+          }
+        }
+        team_sync<true>();
+        pass_frame_lean<1>(fbuf, twl, lane);
+        team_sync<true>();
+        if (fi == FPW - 1 && !kTapsResident) {
+          asm volatile("" ::: "memory");
+          load_taps_pair(p, tid, 0, hp[0]);
+        }
+        last_pass_frame<MAG>(p, fbuf, lane, f0 + fc);
+      }
+      __syncthreads();  // everybody has read the chunk out of LDS
+      if (!more) break;
+      fir_chunk();
+    }
+  }
+
+  // The careful path, for the few runs that touch the history in front of the call's first sample, a partial last chunk
+  // or a buffer the vector loads cannot take: no window kept in registers -- per chunk and column the NW rows are
+  // fetched again, sample by sample with the checks of load_row<false> (all of a column's loads in flight together: a
+  // run of this kind is a straggler among thousands, but a serial one would outlast the whole kernel), columns in a
+  // rolled loop.  Same taps in the same order: the same bits.
+  template <bool MAG>
+  PFB_DEV void twin_careful(const KernelParams& p, float2* lds, const float2* twl, long long f_begin, long long f_end) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const raw_t* in = static_cast<const raw_t*>(p.in);
+    const raw_t* hist = static_cast<const raw_t*>(p.hist);
+    const v2f conj_mul = (v2f){1.f, (p.flags & PFB_FLAG_CONJUGATE_INPUT) ? -1.f : 1.f};
+    for (long long f0 = f_begin; f0 < f_end; f0 += C) {
+      if (!(K::LANES < NT) || tid < K::LANES) {
+#pragma unroll 1
+        for (int cc = 0; cc < CPT; ++cc) {
+          const int c = tid * CPT + cc, n = D - 1 - c;
+          const int pos = (n / K::S(0)) * K::RS(0) + (n % K::S(0));
+          const float* tl = p.taps_lane + (size_t)c * K::WP;
+          raw_t r[NW];
+#pragma unroll
+          for (int i = 0; i < NW; ++i) {
+            const long long fr = f0 - (W - 1) + i;  // frame whose newest row this is
+            const long long s = fr * D + p.base + c;
+            r[i] = (fr >= p.frames) ? raw_t{} : ((s >= 0) ? in[s] : hist[p.hist_samples + s]);
+          }
+          float h[W];
+#pragma unroll
+          for (int j = 0; j < W; ++j) h[j] = tl[j];
+          v2f acc[C];
+#pragma unroll
+          for (int t = 0; t < C; ++t) acc[t] = (v2f){0.f, 0.f};
+#pragma unroll
+          for (int i = NW - 1; i >= 0; --i) {
+            const v2f xi = cvt(r[i]);
+#pragma unroll
+            for (int t = 0; t < C; ++t) {
+              const int j = W - 1 + t - i;
+              if (j >= 0 && j < W) acc[t] = fma2(xi, splat(h[j]), acc[t]);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < C; ++t) reinterpret_cast<v2f*>(lds)[t * K::FS + pos] = acc[t] * conj_mul;
+        }
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int fc = wave; fc < C; fc += NWV) {
+        const long long f = f0 + fc;
+        float2* fbuf = lds + fc * K::FS;
+        if (f < f_end) {
+          pass_frame_lean<0>(fbuf, twl, lane);
+          team_sync<true>();
+          pass_frame_lean<1>(fbuf, twl, lane);
+          team_sync<true>();
+          last_pass_frame<MAG>(p, fbuf, lane, f);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  template <bool MAG>
+  PFB_DEV void run_twin(const KernelParams& p, float2* lds, float2* twl) {
+    const long long G = gridDim.x, fpb = p.frames_per_block;
+    long long r = blockIdx.x;
+    if (p.xcd_remap) {  // consecutive runs on one XCD: a run's halo rows are its predecessor's last rows
+      const long long q = G >> 3, rm = G & 7, xc = r & 7;
+      r = (xc < rm ? xc * (q + 1) : rm * (q + 1) + (xc - rm) * q) + (r >> 3);
+    }
+    const long long nruns = (p.frames + fpb - 1) / fpb;
+    if (r >= nruns) return;
+    // runs [r_lo, r_hi) are whole and have their halo inside `in`: the fast path; the others (the call's first run, a
+    // partial last one, everything if the buffer is not aligned for the vector loads) take the careful one
+    const long long need = (long long)(W - 1) * D - p.base;  // samples of halo in front of frame 0
+    const long long r_lo = need > 0 ? (need + fpb * D - 1) / (fpb * D) : 0;
+    const long long r_hi = p.vec_ok ? p.frames / fpb : 0;
+    fill_twiddles(p, twl);  // (visible behind the chunk loops' first barrier)
+    auto careful = [&](long long rr) {
+      const long long fb = rr * fpb, fl = fb + fpb;
+      twin_careful<MAG>(p, lds, twl, fb, fl < p.frames ? fl : p.frames);
+    };
+    for (; r < nruns && r < r_lo; r += G) careful(r);
+    if (r < r_hi) {
+      twin_fast<MAG>(p, lds, twl, r, G, r_hi);
+      r += ((r_hi - 1 - r) / G + 1) * G;
+    }
+    for (; r < nruns; r += G) careful(r);
   }
 
   // ---- schedule D: sliding windows with the halo shared inside the workgroup -------------------------
@@ -2293,13 +2700,25 @@ hipError_t launch_pairs_sliding(const KernelParams& p, hipStream_t s) {
 // shapes with a FIR-team / FFT-team instantiation: three in-place passes whose last pass fits the FIR team in one
 // iteration per thread or more (the generic pass), a multi-wave FIR team, chunks of C frames = C FFT waves
 template <class K>
-constexpr bool kTeamsOk = K::NP == 3 && !K::PINGPONG && K::NT > 64 && (K::NT + 64 * K::C) <= 1024 &&
+constexpr bool kTeamsOk = !K::WAVE_FRAMES && K::NP == 3 && !K::PINGPONG && K::NT > 64 && (K::NT + 64 * K::C) <= 1024 &&
                           3 * sizeof(float2) * K::BUF <= 160 * 1024 && K::C % 2 == 0;
 
+// schedule 13 (W): independent workgroups of NT/64 waves, a frame per wave and chunk, two or more per CU (run_twin)
 template <class K>
+constexpr bool kTwinOk = K::WAVE_FRAMES && K::NP == 3 && !K::PINGPONG && K::C % (K::NT / 64) == 0 && K::D == K::M && K::CPT % 2 == 0;
+
+template <class K, bool MAG>
+__global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_twin_kernel(const KernelParams p) {
+  __shared__ float2 lds[K::BUF + FastKernel<K>::TWL_ELEMS];
+  FastKernel<K>::template run_twin<MAG>(p, lds, lds + K::BUF);
+}
+
+// MAG: the handle's PFB_FLAG_MAGNITUDE, decided at launch -- inside the kernel the test made the number of stores per
+// step look path-dependent to the compiler, whose s_waitcnt for the row prefetch then also waited for the stores
+template <class K, bool MAG>
 __global__ void __launch_bounds__(K::NT + 64 * K::C, K::MIN_WAVES) pfb_teams_kernel(const KernelParams p) {
   __shared__ float2 bufs[3 * K::BUF];
-  FastKernel<K>::run_teams(p, bufs);
+  FastKernel<K>::template run_teams<0, MAG ? 1 : 0>(p, bufs);
 }
 
 // channel-major for the team plans: the same kernel with its output tile transposed through an L2-resident scratch
@@ -2465,10 +2884,21 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       return hipGetLastError();
     }
   }
+  if constexpr (kTwinOk<K>) {  // independent workgroups, a frame per wave and chunk
+    if (p.schedule == 13) {
+      if (p.layout != PFB_LAYOUT_FRAME_MAJOR) return hipErrorInvalidValue;
+      long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
+      if (p.grid_override > 0 && nb > p.grid_override) nb = p.grid_override;  // resident workgroups walking runs b, b + G, ...
+      if (p.flags & PFB_FLAG_MAGNITUDE) hipLaunchKernelGGL((pfb_twin_kernel<K, true>), dim3((unsigned)nb), dim3(K::NT), 0, s, p);
+      else hipLaunchKernelGGL((pfb_twin_kernel<K, false>), dim3((unsigned)nb), dim3(K::NT), 0, s, p);
+      return hipGetLastError();
+    }
+  }
   if constexpr (kTeamsOk<K>) {  // FIR team + FFT team
     if (p.schedule == 6) {
       const long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
-      hipLaunchKernelGGL(pfb_teams_kernel<K>, dim3((unsigned)nb), dim3(K::NT + 64 * K::C), 0, s, p);
+      if (p.flags & PFB_FLAG_MAGNITUDE) hipLaunchKernelGGL((pfb_teams_kernel<K, true>), dim3((unsigned)nb), dim3(K::NT + 64 * K::C), 0, s, p);
+      else hipLaunchKernelGGL((pfb_teams_kernel<K, false>), dim3((unsigned)nb), dim3(K::NT + 64 * K::C), 0, s, p);
       return hipGetLastError();
     }
   }

@@ -42,6 +42,18 @@ using Cfg560x12i8t =
 using Cfg560x12f32 = FastCfg<560, 12, 560, 1, PFB_FMT_CF32, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;
 using Cfg1024x16f32b = FastCfg<1024, 16, 1024, 1, PFB_FMT_CF32, 8, 3, 8, 8, 16, 128, 128, 65, 1040, false, 1, true>;
 
+// cfg4, schedule W (pfb_fast.hpp): independent workgroups whose waves filter their columns and then transform whole
+// frames by themselves; the window stays packed (raw int16 pairs).  Three shapes of it:
+//   twin    512 threads x 2 columns, chunks of 8 frames (one per wave), 128 registers, 78 KB of LDS: 2 workgroups per CU
+//   triple  256 threads x 4 columns (16-byte loads), chunks of 4 frames, 168 registers, 44 KB: 3 workgroups per CU
+//   duo     256 threads x 4 columns, chunks of 8 frames (two per wave), 256 registers -- taps resident --, 78 KB: 2 per CU
+using Cfg1024x16i16w =
+    FastCfg<1024, 16, 1024, 2, PFB_FMT_INT16_IQ, 8, 3, 16, 16, 4, 64, 68, 260, 1088, false, 4, true, true>;
+using Cfg1024x16i16q =
+    FastCfg<1024, 16, 1024, 4, PFB_FMT_INT16_IQ, 4, 3, 16, 16, 4, 64, 68, 260, 1088, false, 3, true, true>;
+using Cfg1024x16i16d =
+    FastCfg<1024, 16, 1024, 4, PFB_FMT_INT16_IQ, 8, 3, 16, 16, 4, 64, 68, 260, 1088, false, 2, true, true>;
+
 static const FastEntry kRows[] = {
     entry<Cfg1024x16i16t>("pfb_fast<M1024,P16,D1024,int16>", 512, 6),
     entry<Cfg1024x16i16b>("pfb_fast<M1024,P16,D1024,int16,16w>", 256, 0),
@@ -54,6 +66,7 @@ static const FastEntry kRows[] = {
     entry<Cfg560x12i8t>("pfb_fast<M560,P12,D560,int8,teams>", 512, 6),
     entry<Cfg560x12f32>("pfb_fast<M560,P12,D560,cf32>", 252, 0),
     entry<Cfg1024x16f32b>("pfb_fast<M1024,P16,D1024,cf32>", 256, 0),
+    entry<Cfg1024x16i16d>("pfb_fast<M1024,P16,D1024,int16,duo>", 256, 13),
 };
 
 FastTablePart fast_table_big() { return FastTablePart{kRows, (int)(sizeof(kRows) / sizeof(kRows[0]))}; }

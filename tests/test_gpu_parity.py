@@ -292,12 +292,12 @@ def test_fast_and_generic_kernels_agree():
     assert rel(fast, gen) < 2e-6
 
 
-@pytest.mark.parametrize("M,P,nvar", [(1024, 16, 3), (560, 12, 2)])
+@pytest.mark.parametrize("M,P,nvar", [(1024, 16, 4), (560, 12, 2)])
 def test_every_registered_plan_variant_matches_the_oracle(oracle, M, P, nvar):
     """PFB_OPT_VARIANT: the alternative fused plans kept for a shape (cfg4: the FIR-team / FFT-team kernel, 16 waves x
-    1 column 8 x 8 x 16, 8 waves x 2 columns 16 x 16 x 4; M = 560: teams, 9 waves in lockstep) all meet the fp32
-    tolerance, also on a stream that is not a whole number of workgroups; an index past the last registered plan is
-    refused and leaves the handle usable."""
+    1 column 8 x 8 x 16, 8 waves x 2 columns 16 x 16 x 4, independent 4-wave workgroups whose waves transform whole
+    frames; M = 560: teams, 9 waves in lockstep) all meet the fp32 tolerance, also on a stream that is not a whole number
+    of workgroups; an index past the last registered plan is refused and leaves the handle usable."""
     n = M * 700 + 17
     iq = synth.pulsed_iq_numpy(n, 12, np.int16, seed=31)
     h = np.random.default_rng(8).standard_normal(M * P).astype(np.float32) / M
@@ -316,6 +316,33 @@ def test_every_registered_plan_variant_matches_the_oracle(oracle, M, P, nvar):
         ch.reset()
         assert rel(ch(iq), want) < 1e-5
     assert len(names) == nvar
+
+
+@pytest.mark.parametrize("kw", [{}, {"fftshift": True, "conjugate_input": True}, {"magnitude": True}])
+def test_wave_frame_plan_gives_the_team_plan_s_bits(kw):
+    """cfg4's alternative plan (schedule 13: unsynchronised 4-wave workgroups, packed raw window, every wave transforms whole
+    frames by itself; one workgroup per run or resident workgroups chaining short runs) against the default team plan: same
+    taps in the same order through the same passes, so the outputs are bit-identical -- one shot with a ragged tail (the
+    careful path takes the run that touches the history and the partial last chunk), two calls cut at an odd sample (the
+    second call is misaligned for the vector loads: every run takes the careful path), several run lengths."""
+    M, P = 1024, 16
+    n = M * 1500 + 5
+    iq = synth.pulsed_iq_numpy(n, 12, np.int16, seed=77)
+    h = np.random.default_rng(3).standard_normal(M * P).astype(np.float32) / M
+    with Channelizer(M, taps=h, bit_width=12, **kw) as ch:
+        ref = ch(iq)
+        assert "int16>" in ch.last_kernel
+        ch.set_option(L.PFB_OPT_VARIANT, 3)
+        for fpb, grid in ((0, 0), (8, 0), (24, 0), (200, 0), (16, 24), (64, 7)):
+            ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, fpb)
+            ch.set_option(L.PFB_OPT_GRID, grid)
+            ch.reset()
+            got = ch(iq)
+            assert ch.last_kernel.endswith("duo>")
+            assert np.array_equal(got, ref), (fpb, grid)
+            ch.reset()
+            cut = M * 611 + 3
+            assert np.array_equal(np.concatenate([ch(iq[:cut]), ch(iq[cut:])]), ref), (fpb, grid, "two calls")
 
 
 @pytest.mark.parametrize("M,P,D,fmt,bw,P_fused", [(64, 8, 64, "int16", 12, 12), (64, 5, 64, "int8", 8, 12), (256, 6, 256, "int8", 8, 8),
@@ -403,7 +430,7 @@ def test_bench_stream_prefix_of_2e20_samples(oracle, M, P, D, fmt, bw):
 
 @pytest.mark.parametrize("M,P,D,fmt,bw,log2n", [(64, 12, 64, "int16", 12, 30), (64, 12, 64, "int16", 12, 31), (64, 12, 64, "int16", 12, 33),
                                                 (256, 8, 256, "int8", 8, 30),
-                                                (1024, 16, 1024, "int16", 16, 28), (128, 12, 64, "int16", 12, 28),
+                                                (1024, 16, 1024, "int16", 16, 30), (128, 12, 64, "int16", 12, 28),
                                                 (56, 12, 56, "int16", 12, 26), (560, 12, 560, "int16", 12, 26)])
 def test_large_stream_interior_windows(oracle, M, P, D, fmt, bw, log2n):
     """BASELINE.json's full sizes through size-independent checks: run the whole synthetic stream
@@ -437,6 +464,35 @@ def test_large_stream_interior_windows(oracle, M, P, D, fmt, bw, log2n):
         assert bool(torch.isfinite(torch.view_as_real(part)).all())
     del y, iq
     torch.cuda.empty_cache()
+
+
+def test_cfg1_as_the_example_script_calls_it(oracle):
+    """BASELINE config 1 the way /root/reference/matlab/channelizer_example.m runs it: M = 8 (12 taps per band = the
+    96-tap prototype), complex float input, `iq'` (conjugated, :23), ONE stateful System object (:31) fed overlapping
+    windows of 5 ms = 5000 frames hopped by 100 frames (:33-34, :50-53), `abs` (:56) and `fftshift(., 2)` (:58) -- 10^6
+    samples, every window compared.  The object keeps its filter state across the overlapping calls (the first 11 frames
+    of every window are computed from the PREVIOUS window's tail): the oracle, which has no state,
+    is fed [previous window's last M*P samples | window] and its first P frames are dropped -- the same call sequence."""
+    M, P, N = 8, 12, 10 ** 6
+    win, hop = 5000 * M, 100 * M
+    q = synth.pulsed_iq_numpy(N, 12, np.int16, seed=5)
+    iq = (q.astype(np.float32) / np.float32(2048.0))  # (N, 2) float32: what the script holds after :18-21
+    x = iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)
+    h = oracle.design_prototype(M, P).astype(np.float32)
+    cfg = OracleConfig(M, P, M, conj_input=True, fftshift=True)
+    worst, calls = 0.0, 0
+    with Channelizer(M, taps=h, sample_format="cf32", conjugate_input=True, magnitude=True, fftshift=True) as ch:
+        tail = np.zeros(M * P, dtype=np.complex128)  # a fresh object: zero state
+        for ii in range(0, N - win + 1, hop):
+            got = ch(iq[ii:ii + win])
+            assert got.shape == (win // M, M) and got.dtype == np.float32
+            want = np.abs(oracle.channelize(np.concatenate([tail, x[ii:ii + win]]), h.astype(np.float64), cfg, "fft"))[P:]
+            worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))
+            tail = x[ii + win - M * P:ii + win]
+            calls += 1
+        assert ch.last_kernel == "pfb_fast<M8,P12,D8,cf32>"
+    assert calls == (N - win) // hop + 1 == 1201
+    assert worst < REL_TOL, worst
 
 
 @pytest.mark.parametrize("opts", [{L.PFB_OPT_SCHEDULE: 0}, {L.PFB_OPT_SCHEDULE: 0, L.PFB_OPT_FRAMES_PER_BLOCK: 40},

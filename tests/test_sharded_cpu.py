@@ -57,9 +57,12 @@ class OracleBackedChannelizer:
         receiving = self.world > 1 and (self.ring or self.rank > 0)
         sending = self.world > 1 and (self.ring or self.rank + 1 < self.world)
         tail = np.ascontiguousarray(seg[-HALO:])
+        # the last rank of a ring passes its carried state on (the library's rule, include/pfb_channelizer.h): its
+        # successor, rank 0, works on the NEXT call's first segment
+        passed = np.ascontiguousarray(self.state) if (self.ring and self.rank == self.world - 1) else tail
         halo = np.zeros((HALO, 2), np.int16)
         if sending or receiving:
-            rc = self.exchange(tail.ctypes.data if sending else 0, halo.ctypes.data if receiving else 0, HALO * 4,
+            rc = self.exchange(passed.ctypes.data if sending else 0, halo.ctypes.data if receiving else 0, HALO * 4,
                                (self.rank + 1) % self.world if sending else -1,
                                (self.rank - 1) % self.world if receiving else -1, 0)
             assert rc == 0
@@ -89,16 +92,24 @@ def _worker(rank, world, port, total, taps, mode, ret):
         sc = ShardedChannelizer(ch, rank, world, mode=mode)  # the library's callback contract over gloo, host pointers
         y = sc.process_segment(seg, first_frame=s // D)
         got_halo = ch.last_halo.copy()
-        # ring variant used by bench.py: everyone receives, rank 0 from the last rank
+        # ring variant used by bench.py: everyone receives, rank 0 from the last rank -- an ENDLESS stream, so two calls
+        # with different data: call 2 of rank r is segment world + r of the stream
         ring = OracleBackedChannelizer(taps)
-        ShardedChannelizer(ring, rank, world, mode=mode, ring=True).process_segment(seg, first_frame=s // D)
+        rsc = ShardedChannelizer(ring, rank, world, mode=mode, ring=True)
+        y1 = rsc.process_segment(seg, first_frame=s // D)  # (resets: the stream starts here)
+        ring_halo1 = ring.last_halo.copy()
+        s2 = total + s
+        seg2 = torch.from_numpy(synth.pulsed_iq_numpy(e - s, BW, np.int16, seed=4, start=s2))
+        y2 = rsc.process_segment(seg2, first_frame=s2 // D, reset=False)
+        ring_halo2 = ring.last_halo.copy()
         # the tensor-level helpers agree with each other
         halo = torch.zeros((HALO, 2), dtype=torch.int16)
         exchange_halo(seg[-HALO:].contiguous(), halo, rank, world, ring=True)
         halo2 = torch.zeros((HALO, 2), dtype=torch.int16)
         exchange_halo_allgather(seg[-HALO:].contiguous(), halo2, rank, world)
-        assert torch.equal(halo2, halo) and np.array_equal(ring.last_halo, halo.numpy())
-        ret[rank] = (np.asarray(y), halo.numpy().copy(), seg.numpy()[-HALO:].copy(), got_halo)
+        assert torch.equal(halo2, halo)
+        ret[rank] = (np.asarray(y), halo.numpy().copy(), seg.numpy()[-HALO:].copy(), got_halo,
+                     np.asarray(y1), np.asarray(y2), ring_halo1, ring_halo2, seg2.numpy()[-HALO:].copy())
     finally:
         dist.destroy_process_group()
 
@@ -125,8 +136,19 @@ def test_two_rank_time_sharding_matches_single_stream(mode, world):
     sharded = np.concatenate([ret[r][0] for r in range(world)])
     assert sharded.shape == single.shape
     assert np.array_equal(sharded, single)  # raw-sample halo => identical bits
-    for r in range(world):  # ring: each rank holds its predecessor's tail
+    for r in range(world):  # the tensor-level ring helper: each rank holds its predecessor's tail
         assert np.array_equal(ret[r][1], ret[(r - 1) % world][2])
+    # the ring as the library runs it (an endless stream: call 2 continues call 1): two calls of `world` segments each
+    # equal ONE pass over the 2 * total samples, bit for bit; rank 0 started from zero state and, in call 2, from the last
+    # rank's tail of call 1 -- never from the last rank's CURRENT tail
+    iq2 = np.concatenate([synth.pulsed_iq_numpy(e - s, BW, np.int16, seed=4, start=total + s)
+                          for s, e in segment_bounds(total, world, D)])
+    both = o.channelize(o.unpack(np.concatenate([iq, iq2]), BW), taps, OracleConfig(M, P, D))
+    ring_rows = np.concatenate([ret[r][4] for r in range(world)] + [ret[r][5] for r in range(world)])
+    assert np.array_equal(ring_rows, both)
+    assert not ret[0][6].any() and np.array_equal(ret[0][7], ret[world - 1][2])
+    for r in range(1, world):
+        assert np.array_equal(ret[r][6], ret[r - 1][2]) and np.array_equal(ret[r][7], ret[r - 1][8])
     # open chain: rank 0 continued from its own (zero) state, rank r from exactly M*P - D samples of rank r - 1
     assert not ret[0][3].any()
     for r in range(1, world):
