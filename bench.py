@@ -35,6 +35,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 
 WORKLOADS = {
     # name: (M, P, D, fmt, bit_width, bytes_in_per_sample, log2 samples of the BASELINE.json configuration)
+    # cfg1 is channelizer_example.m's own shape (M = 8, the 96-tap prototype, complex float input); BASELINE runs it on
+    # the CPU at 10^6 samples -- here a 2^28-sample device-resident stream, so that it is a bandwidth figure
+    "cfg1": (8, 12, 8, "cf32", 0, 8, 28),
     "cfg2": (64, 12, 64, "int16", 12, 4, 30),
     "cfg3": (256, 8, 256, "int8", 8, 2, 30),
     "cfg4": (1024, 16, 1024, "int16", 16, 4, 30),
@@ -43,7 +46,7 @@ WORKLOADS = {
     "ref560": (560, 12, 560, "int16", 12, 4, 28),
 }
 # what the default N = 1 run times after the headline: (workload, channel_major)
-OTHER_WORKLOADS = [("cfg3", False), ("cfg4", False), ("cfg5", False), ("ref56", False), ("ref560", False),
+OTHER_WORKLOADS = [("cfg1", False), ("cfg3", False), ("cfg4", False), ("cfg5", False), ("ref56", False), ("ref560", False),
                    ("cfg2", True), ("cfg3", True), ("cfg4", True), ("cfg5", True)]
 TRAFFIC_SOURCE = "profiles/r02_pmc_traffic.json"  # rocprofv3 --pmc passes of this command (never measured in-run)
 
@@ -192,7 +195,7 @@ def main() -> None:
     def make_handle(name: str, channel_major: bool, tuned: bool):
         M, P, D, fmt, bw, _bytes_in, _ = WORKLOADS[name]
         taps = design_prototype(M, P, 80.0)
-        ch = Channelizer(M, taps=taps, decimation=D, sample_format=fmt, bit_width=bw, device=local_rank,
+        ch = Channelizer(M, taps=taps, decimation=D, sample_format=fmt, bit_width=max(bw, 1), device=local_rank,
                          channel_major=channel_major)
         ch.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         ch.set_option(L.PFB_OPT_KERNEL, 2)  # the hand-written fast kernel or nothing
@@ -217,7 +220,9 @@ def main() -> None:
         M, P, D, fmt, bw, _bytes_in, _ = WORKLOADS[name]
         n = 1 << log2n
         tdtype = torch.int8 if fmt == "int8" else torch.int16
-        iq = synth.pulsed_iq_torch(n, bw, tdtype, seed=synth.SEED, device=dev, start=start)
+        iq = synth.pulsed_iq_torch(n, bw if bw else 12, tdtype, seed=synth.SEED, device=dev, start=start)
+        if fmt == "cf32":  # what the example script holds after its normalisation (channelizer_example.m:18-21)
+            iq = iq.to(torch.float32) / 2048.0
         F = n // D + 1  # +1: with M not a power of two the carried tail completes an extra frame every few steps
         out = torch.empty((M, F) if channel_major else (F, M), dtype=torch.complex64, device=dev)
         return iq, out
@@ -278,12 +283,77 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    def gather_floats(vals):
+        """every rank's list of floats -> [world][len] on every rank (one small all_gather)"""
+        if world == 1:
+            return [list(vals)]
+        t = torch.tensor(list(vals), dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        return [x.cpu().tolist() for x in parts]
+
+    headline_kernel = ch.last_kernel
+    my_k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    per_rank_kernel_ms = [v[0] for v in gather_floats([my_k_ms])]
+
+    # ---- N > 1: BASELINE's 8-GPU configuration is cfg4 (M = 1024, 16 taps, 2^30 samples per GPU, halo 61 440 B): a short
+    # sharded pass of it after the headline, every rank taking part
+    sharded_cfg4 = None
+    if world > 1 and not args.no_other_workloads and args.workload != "cfg4":
+        ch.release()
+        del iq, out
+        torch.cuda.empty_cache()
+        ch = iq = out = None
+        try:
+            c4M, c4P, c4D, c4fmt, c4bw, c4bytes, c4log2 = WORKLOADS["cfg4"]
+            l2 = min(c4log2, args.log2_samples)
+            n4 = 1 << l2
+            c4, _ = make_handle("cfg4", False, tuned=False)
+            iq4, out4 = make_buffers("cfg4", l2, False, start=rank * n4)
+            c4.attach_shard(rank, world, make_exchange(rank, world, None, args.halo, local_rank), ring=True)
+            out4 = out4.reshape(-1)[: (n4 // c4D) * c4M].reshape(n4 // c4D, c4M)
+            halo4 = c4.halo_samples
+            for _ in range(6):
+                c4.process_shard(iq4, out=out4)
+            c4.sync()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            c4.set_option(L.PFB_OPT_PROFILE, 1)
+            k4 = 10
+            tq = time.perf_counter()
+            for _ in range(k4):
+                c4.process_shard(iq4, out=out4)
+            c4.sync()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            wall4 = time.perf_counter() - tq
+            ms4 = kernel_ms_per_step(c4, 2)
+            c4.set_option(L.PFB_OPT_PROFILE, 0)
+            kname4 = c4.last_kernel
+            c4.release()
+            del iq4, out4
+            torch.cuda.empty_cache()
+            g = gather_floats([float(np.mean(ms4)), wall4])
+            k_all = [v[0] for v in g]
+            wall_max = max(v[1] for v in g)
+            b4 = c4bytes + 8 * (c4M // c4D)
+            sharded_cfg4 = {"workload": "cfg4", "layout": "frame-major", "sharded": f"time-sharded x{world} (ring), {args.backend} ({args.halo})",
+                            "shape": f"M={c4M} P={c4P} D={c4D} {c4fmt}, 2^{l2} samples per GPU per step", "kernel": kname4,
+                            "halo_samples": int(halo4), "halo_bytes": int(halo4 * c4bytes), "launches_per_step": 2, "steps": k4,
+                            "kernel_ms_per_rank": {"min": round(min(k_all), 4), "max": round(max(k_all), 4),
+                                                   "all": [round(v, 4) for v in k_all]},
+                            "step_wall_ms": round(wall_max / k4 * 1e3, 4),
+                            "ms_value": round(world * n4 * k4 / wall_max / 1e6, 1),
+                            "frac_slowest_rank": round(n4 * b4 / (max(k_all) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "algorithmic_bytes_per_sample": b4}
+        except Exception as e:  # a failing side pass must not cost the headline line (every rank fails alike or not at all)
+            sharded_cfg4 = {"workload": "cfg4", "sharded": f"x{world}", "error": repr(e)}
+
     if rank == 0:
         value = world * n * args.steps / elapsed / 1e6
         bytes_per_sample = bytes_in + 8 * (M // D)            # SURVEY.md section 8d: B = bytes_in + 8*(M/D)
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = n * bytes_per_sample / (k_ms * 1e-3) / 1e9  # algorithmic bytes per launch / avg launch time
-        headline_kernel = ch.last_kernel
         res = {
             "metric": "input MS/s (complex) channelized",
             "value": round(value, 1),
@@ -316,6 +386,12 @@ def main() -> None:
                          "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_sample": bytes_per_sample},
         }
+        if world > 1:  # `frac` above is rank 0's kernels; the spread over ranks (one all_gather of the means):
+            res["roofline"]["kernel_ms_per_rank"] = {"min": round(min(per_rank_kernel_ms), 4), "max": round(max(per_rank_kernel_ms), 4),
+                                                     "all": [round(v, 4) for v in per_rank_kernel_ms]}
+            res["roofline"]["frac_slowest_rank"] = round(n * bytes_per_sample / (max(per_rank_kernel_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if sharded_cfg4 is not None:
+                res["other_workloads"] = [sharded_cfg4]
         tfile = os.path.join(ROOT, TRAFFIC_SOURCE)
         if os.path.exists(tfile) and args.workload == "cfg2" and args.log2_samples == 30 and not args.channel_major:
             try:
@@ -353,7 +429,8 @@ def main() -> None:
                         bounds[f"1_read_{ratio}_written_{spw}_rows_per_wave"] = round(bps.value / 1e9 / HBM_PEAK_GBS, 4)
             res["roofline"]["copy_kernel_frac_by_byte_mix"] = bounds
         prefix = iq[: 1 << 28].cpu().numpy() if (world == 1 and not args.no_cpu_baseline and fmt == "int16") else None
-        ch.release()
+        if ch is not None:
+            ch.release()
         del iq, out
         torch.cuda.empty_cache()
 
@@ -418,7 +495,7 @@ def main() -> None:
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    else:
+    elif ch is not None:
         ch.release()
     if world > 1:
         dist.barrier()

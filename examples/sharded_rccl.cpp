@@ -32,9 +32,11 @@ static int exchange(void* user, const void* d_send, void* d_recv, size_t bytes, 
   Peer* p = static_cast<Peer*>(user);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (ncclGroupStart() != ncclSuccess) return 1;
-  if (send_to >= 0 && ncclSend(d_send, bytes, ncclUint8, send_to, p->comm, s) != ncclSuccess) return 2;
-  if (recv_from >= 0 && ncclRecv(d_recv, bytes, ncclUint8, recv_from, p->comm, s) != ncclSuccess) return 3;
-  return ncclGroupEnd() == ncclSuccess ? 0 : 4;
+  int rc = 0;  // the group is ALWAYS closed: an open group would swallow every later RCCL call of this thread
+  if (send_to >= 0 && ncclSend(d_send, bytes, ncclUint8, send_to, p->comm, s) != ncclSuccess) rc = 2;
+  if (rc == 0 && recv_from >= 0 && ncclRecv(d_recv, bytes, ncclUint8, recv_from, p->comm, s) != ncclSuccess) rc = 3;
+  if (ncclGroupEnd() != ncclSuccess && rc == 0) rc = 4;
+  return rc;  // the first failure; non-zero makes pfb_process_shard_async return PFB_ERR_COMM
 }
 
 int main(int argc, char** argv) {

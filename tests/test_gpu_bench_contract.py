@@ -47,3 +47,11 @@ def test_two_ranks_start_themselves_and_print_one_line(halo):
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0 and d["cpu_baseline"] is None
     assert "time-sharded x2" in d["config"]["parallelism"] and "704 raw samples" in d["config"]["parallelism"]
     assert d["roofline"]["launches_per_step"] == 2 and d["roofline"]["launches_timed"] == 4
+    # the spread over ranks of the headline, and BASELINE's 8-GPU configuration (cfg4) as a sharded side pass
+    kr = d["roofline"]["kernel_ms_per_rank"]
+    assert len(kr["all"]) == 2 and 0 < kr["min"] <= kr["max"] and d["roofline"]["frac_slowest_rank"] > 0
+    (c4,) = d["other_workloads"]
+    assert c4["workload"] == "cfg4" and "error" not in c4, c4
+    assert c4["halo_bytes"] == 61440 and c4["halo_samples"] == 15360 and c4["launches_per_step"] == 2
+    assert len(c4["kernel_ms_per_rank"]["all"]) == 2 and c4["kernel_ms_per_rank"]["min"] > 0 and c4["step_wall_ms"] > 0
+    assert c4["kernel"].startswith("pfb_fast<M1024,P16") and c4["ms_value"] > 0

@@ -34,27 +34,57 @@ def hip_memcpy_async(dst, src, nbytes, stream):
 
 
 class Mailbox:
-    """Single-process stand-in for the transport: rank r's send parks its tail in slot r (a copy on the side stream, so
-    the sender's segment may change afterwards); rank r+1's receive copies slot r into the landing zone."""
+    """Single-process stand-in for a MATCHED transport (what ncclSend / ncclRecv or batch_isend_irecv are): the `world`
+    handles run their shard calls on `world` host threads (ctypes drops the GIL around the library call; the callback
+    takes it back), and inside the callbacks rank r's send of call i meets rank r+1's receive of call i -- sends park
+    the tail in slot r (a copy on the side stream the library handed over, waited for), everybody meets at a barrier,
+    receives copy their predecessor's slot into the landing zone, and a second barrier keeps call i+1's sends out of the
+    slots until everyone has read."""
 
     def __init__(self, world, nbytes):
+        import threading
         import torch
+        self.world = world
         self.slots = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(world)]
         self.calls = []
+        self.barrier = threading.Barrier(world)
 
     def exchange_for(self, rank):
         def exchange(d_send, d_recv, nbytes, send_to, recv_from, stream):
             import torch
             self.calls.append((rank, bool(d_send), bool(d_recv), nbytes, send_to, recv_from))
-            if recv_from >= 0:  # ranks run in order here, so the predecessor's tail is already parked
-                assert d_recv
-                hip_memcpy_async(d_recv, self.slots[recv_from].data_ptr(), nbytes, stream)
             if send_to >= 0:
                 assert d_send
                 hip_memcpy_async(self.slots[rank].data_ptr(), d_send, nbytes, stream)
-                torch.cuda.synchronize()  # the next rank's receive runs on another stream: park the tail first
+                torch.cuda.synchronize()
+            self.barrier.wait(timeout=60)
+            if recv_from >= 0:
+                assert d_recv
+                hip_memcpy_async(d_recv, self.slots[recv_from].data_ptr(), nbytes, stream)
+                torch.cuda.synchronize()
+            self.barrier.wait(timeout=60)
             return 0
         return exchange
+
+    def run(self, fns):
+        """fns[r](): rank r's shard call; all of them at once, like `world` processes."""
+        import threading
+        out, err = [None] * len(fns), []
+
+        def go(r):
+            try:
+                out[r] = fns[r]()
+            except Exception as e:  # noqa: BLE001
+                err.append((r, repr(e)))
+                self.barrier.abort()
+
+        ts = [threading.Thread(target=go, args=(r,)) for r in range(len(fns))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not err, err
+        return out
 
 
 @pytest.mark.parametrize("M,P,D,fmt,bw,kw", [
@@ -84,27 +114,37 @@ def test_sharded_handles_equal_single_stream_bit_exact(M, P, D, fmt, bw, kw):
             assert halo == (P - 1) * M  # north star: the (taps_per_branch - 1) * M overlap samples only
     d_iq = torch.from_numpy(iq).cuda()
     box = Mailbox(G, halo * (2 if fmt == "int8" else 4))
-    outs = []
-    for g in range(G):  # one handle per shard, as on G devices
-        with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, **kw) as sh:
-            sh.attach_shard(g, G, box.exchange_for(g), ring=False)
-            sh.set_frame_index(g * seg_frames)
-            y = sh.process_shard(d_iq[g * seg_frames * D:(g + 1) * seg_frames * D])
-            sh.sync()
-            outs.append(y.cpu().numpy())
+    hs = [Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, **kw) for _ in range(G)]  # one handle per shard, as on G devices
+    try:
+        def call(g):
+            def f():
+                hs[g].attach_shard(g, G, box.exchange_for(g), ring=False)
+                hs[g].set_frame_index(g * seg_frames)
+                y = hs[g].process_shard(d_iq[g * seg_frames * D:(g + 1) * seg_frames * D])
+                hs[g].sync()
+                return y.cpu().numpy()
+            return f
+        outs = box.run([call(g) for g in range(G)])
+    finally:
+        for x in hs:
+            x.release()
     got = np.concatenate(outs, axis=1 if cm else 0)
     assert got.shape == one.shape and np.array_equal(got, one)
     # open chain: rank 0 receives nothing, the last rank sends nothing; everyone else both
-    assert [(c[0], c[1], c[2]) for c in box.calls] == [(0, True, False), (1, True, True), (2, False, True)]
+    assert sorted((c[0], c[1], c[2]) for c in box.calls) == [(0, True, False), (1, True, True), (2, False, True)]
 
 
-def test_ring_shard_continues_the_previous_batch_and_updates_state():
-    """ring=True (what bench.py times): rank 0's halo is the last rank's tail of the batch before, so batch after batch
-    is one endless stream; and after a shard call the handle's own state is the segment's tail, as after pfb_process."""
+@pytest.mark.parametrize("G", [2, 3])
+def test_ring_shard_continues_the_previous_batch_and_updates_state(G):
+    """ring=True (what bench.py times): rank 0's halo is the last rank's tail of the batch BEFORE -- the last rank passes
+    on its carried state, because a matched transport pairs its send of call i with rank 0's receive of call i --, so
+    batch after batch (different data every batch) is one endless stream; and after a shard call the handle's own state
+    is the segment's tail, as after pfb_process."""
     import torch
-    M, P, D, G, F = 64, 12, 64, 2, 500
+    M, P, D, F = 64, 12, 64, 500
     h = np.random.default_rng(9).standard_normal(M * P).astype(np.float32)
-    iq = synth.pulsed_iq_numpy(2 * G * F * D, 12, np.int16, seed=3)  # two batches of G segments
+    NB = 3
+    iq = synth.pulsed_iq_numpy(NB * G * F * D, 12, np.int16, seed=3)  # NB batches of G segments
     with Channelizer(M, taps=h, bit_width=12) as ch:
         one = ch(iq)
     d_iq = torch.from_numpy(iq).cuda()
@@ -114,19 +154,23 @@ def test_ring_shard_continues_the_previous_batch_and_updates_state():
         for g in range(G):
             hs[g].attach_shard(g, G, box.exchange_for(g), ring=True)
         rows = []
-        for batch in range(2):
-            for g in range(G):
-                s = (batch * G + g) * F * D
-                rows.append(hs[g].process_shard(d_iq[s:s + F * D]))
-                hs[g].sync()
+        for batch in range(NB):
+            def call(g, batch=batch):
+                def f():
+                    s = (batch * G + g) * F * D
+                    y = hs[g].process_shard(d_iq[s:s + F * D])
+                    hs[g].sync()
+                    return y
+                return f
+            rows += box.run([call(g) for g in range(G)])
         got = torch.cat(rows).cpu().numpy()
-        # the very first segment received the (zero) parked slot of the last rank = stream start; everything after
-        # continues bit-exactly across segment AND batch boundaries
+        # the very first segment received the last rank's (zero) state = stream start; everything after continues
+        # bit-exactly across segment AND batch boundaries
         assert np.array_equal(got, one)
         # state after a shard call = the segment's tail: a plain call continues the stream
         tail_in = synth.pulsed_iq_numpy(D * 40, 12, np.int16, seed=77)
         with Channelizer(M, taps=h, bit_width=12) as ref:
-            ref(iq[: (G + G) * F * D])  # same history as hs[G-1] now has
+            ref(iq[: NB * G * F * D])  # same history as hs[G-1] now has
             want = ref(tail_in)
         assert np.array_equal(hs[G - 1](tail_in), want)
     finally:
@@ -214,6 +258,13 @@ for mode in ("p2p", "allgather"):
     with Channelizer(M, taps=h, bit_width=12, device=rank) as ch:
         y = ShardedChannelizer(ch, rank, world, mode=mode).process_segment(seg, first_frame=rank * F)
         np.save(os.path.join({out!r}, f"shard_{{mode}}_{{rank}}.npy"), y.cpu().numpy())
+    # the ring (bench.py's mode): two calls with different data = segments rank and world + rank of one endless stream
+    with Channelizer(M, taps=h, bit_width=12, device=rank) as ch:
+        sc = ShardedChannelizer(ch, rank, world, mode=mode, ring=True)
+        ya = sc.process_segment(seg, first_frame=rank * F)
+        seg2 = synth.pulsed_iq_torch(F * D, 12, torch.int16, device=torch.device("cuda", rank), start=(world + rank) * F * D)
+        yb = sc.process_segment(seg2, first_frame=(world + rank) * F, reset=False)
+        np.save(os.path.join({out!r}, f"ring_{{mode}}_{{rank}}.npy"), np.concatenate([ya.cpu().numpy(), yb.cpu().numpy()]))
 dist.destroy_process_group()
 """
 
@@ -237,12 +288,70 @@ def test_two_devices_over_rccl_equal_one_device(tmp_path):
     assert [p.wait(timeout=500) for p in procs] == [0, 0]
     M, P, D, F = 64, 12, 64, 4096
     h = np.random.default_rng(1).standard_normal(M * P).astype(np.float32)
-    iq = synth.pulsed_iq_counter_numpy(2 * F * D, 12, np.int16)
+    iq = synth.pulsed_iq_counter_numpy(4 * F * D, 12, np.int16)
     with Channelizer(M, taps=h, bit_width=12, device=0) as ch:
-        one = ch(iq)
+        two = ch(iq)
+    one = two[: 2 * F]
     for mode in ("p2p", "allgather"):
         got = np.concatenate([np.load(tmp_path / f"shard_{mode}_{r}.npy") for r in range(2)])
         assert np.array_equal(got, one), mode
+        ring = [np.load(tmp_path / f"ring_{mode}_{r}.npy") for r in range(2)]
+        got = np.concatenate([ring[0][:F], ring[1][:F], ring[0][F:], ring[1][F:]])
+        assert np.array_equal(got, two), (mode, "ring")
+
+
+_WRAP_WORKER = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from sdr_channelizer_amd import sharded
+rank, world = int(os.environ["RANK"]), 2
+torch.cuda.set_device(0)  # both ranks on the box's one GPU: gloo carries the bytes (RCCL refuses two ranks per device)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+hip = C.CDLL("libamdhip64.so")
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+n = 61440  # cfg4's halo in bytes
+a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+for p in (a, b, c):
+    assert hip.hipMalloc(C.byref(p), n) == 0
+pattern = lambda r: bytes((7 * i + 3 + 11 * r) % 251 for i in range(n))
+src = (C.c_ubyte * n).from_buffer_copy(pattern(rank))
+assert hip.hipMemcpy(a, src, n, 1) == 0
+snd, rcv, rcv2 = (sharded._wrap(p.value, n, 0) for p in (a, b, c))  # library-style raw device pointers
+assert snd.is_cuda and snd.dtype == torch.uint8 and snd.numel() == n and snd.data_ptr() == a.value
+other = 1 - rank
+sharded._p2p(snd, rcv, other, other)                  # neighbour exchange, as make_exchange's callback does
+sharded._allgather(snd, rcv2, n, rank, world, other)  # the same as one collective
+torch.cuda.synchronize()
+for p in (b, c):
+    back = (C.c_ubyte * n)()
+    assert hip.hipMemcpy(back, p, n, 2) == 0
+    assert bytes(back) == pattern(other)
+dist.barrier()
+dist.destroy_process_group()
+print("wrap ok", rank)
+"""
+
+
+def test_halo_transport_wraps_raw_device_pointers(tmp_path):
+    """sharded._wrap hands LIBRARY-owned device memory (a raw hipMalloc pointer, as pfb_halo_recv_buffer returns) to
+    torch.distributed through __cuda_array_interface__; _p2p / _allgather then move it.  The CPU tests drive these
+    functions with host pointers and the two-GPU test skips on this pool: here they run on raw device pointers, two
+    fresh rank processes sharing the box's GPU over gloo."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "wrap_worker.py"
+    script.write_text(_WRAP_WORKER.format(root=ROOT))
+    procs = []
+    for r in range(2):
+        env = dict({k: v for k, v in os.environ.items() if k not in ("LOCAL_RANK",)}, RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert all("wrap ok" in o for o in outs), outs
 
 
 def test_cpp_host_shards_over_every_gpu_with_rccl(tmp_path):
