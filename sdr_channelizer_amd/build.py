@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libpfb_channelizer.so")
-SOURCES = ["pfb_api.cpp", "pfb_kernels.hip", "pfb_kernels_mid.hip", "pfb_kernels_big.hip", "pfb_pdw.hip", "iq_packet.c"]
+SOURCES = ["pfb_api.cpp", "pfb_kernels.hip", "pfb_kernels_mid.hip", "pfb_kernels_big.hip", "pfb_kernels_mixed.hip", "pfb_pdw.hip", "iq_packet.c"]
 HEADERS = ["pfb_common.h", "pfb_fast.hpp", "pfb_table.h"]
 ARCH = "gfx950"
 
@@ -62,7 +62,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
 
     # the kernel translation units dominate (tens of seconds each): compile them side by side
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as pool:
         list(pool.map(compile_one, jobs))
     tmp = LIB + ".tmp"
     subprocess.check_call([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp] + objs)

@@ -223,6 +223,51 @@ template <> struct Dft<10> {
   }
 };
 
+// 3-, 6- and 12-point DFTs: band counts with a factor 3 (numBands = fs * 1e-6 at 12, 24, 30, 48, 96, 120 Msps,
+// channelizer_example.m:29).  W_3 = e^{+j 2 pi / 3} = -1/2 + j sqrt(3)/2.
+template <> struct Dft<3> {
+  PFB_DEV void run(v2f (&x)[3]) {
+    constexpr float s = 0.86602540378443865f;
+    const v2f p = x[1] + x[2], d = x[1] - x[2];
+    const v2f a = fma2(p, splat(-0.5f), x[0]), b = d * splat(s);
+    x[0] = x[0] + p;
+    x[1] = add_j(a, b);
+    x[2] = sub_j(a, b);
+  }
+};
+
+template <> struct Dft<6> {
+  PFB_DEV void run(v2f (&x)[6]) {
+    constexpr float s = 0.86602540378443865f;
+    v2f e[3] = {x[0], x[2], x[4]}, o[3] = {x[1], x[3], x[5]};
+    Dft<3>::run(e);
+    Dft<3>::run(o);
+    const v2f t1 = cmul(o[1], 0.5f, s), t2 = cmul(o[2], -0.5f, s);  // W_6^1, W_6^2
+    x[0] = e[0] + o[0]; x[3] = e[0] - o[0];
+    x[1] = e[1] + t1;   x[4] = e[1] - t1;
+    x[2] = e[2] + t2;   x[5] = e[2] - t2;
+  }
+};
+
+template <> struct Dft<12> {
+  PFB_DEV void run(v2f (&x)[12]) {
+    constexpr float s = 0.86602540378443865f;
+    v2f e[6], o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { e[k] = x[2 * k]; o[k] = x[2 * k + 1]; }
+    Dft<6>::run(e);
+    Dft<6>::run(o);
+    // W_12^k = e^{+j 2 pi k / 12}: (s, 1/2), (1/2, s), j, (-1/2, s), (-s, 1/2)
+    const v2f t1 = cmul(o[1], s, 0.5f), t2 = cmul(o[2], 0.5f, s), t4 = cmul(o[4], -0.5f, s), t5 = cmul(o[5], -s, 0.5f);
+    x[0] = e[0] + o[0];       x[6] = e[0] - o[0];
+    x[1] = e[1] + t1;         x[7] = e[1] - t1;
+    x[2] = e[2] + t2;         x[8] = e[2] - t2;
+    x[3] = add_j(e[3], o[3]); x[9] = sub_j(e[3], o[3]);
+    x[4] = e[4] + t4;         x[10] = e[4] - t4;
+    x[5] = e[5] + t5;         x[11] = e[5] - t5;
+  }
+};
+
 // 14 = 2 x 7 (560 = 14 x 10 x 4 keeps every non-final pass of the team kernel at one item per lane)
 template <> struct Dft<14> {
   PFB_DEV void run(v2f (&x)[14]) {
@@ -290,7 +335,10 @@ struct FastCfg {
   static constexpr int K(int i) { int k = 1; for (int j = 0; j < i; ++j) k *= R(j); return k; }
   static constexpr int WP = (W + 3) / 4 * 4;  // taps per column padded to whole float4s
   static constexpr int TAPS_LANE_FLOATS = D * WP;  // per-column tap table built by init_tables
-  static constexpr int TW_OFF(int i) { int o = 0; for (int j = 0; j < i; ++j) o += S(j) * R(j); return o; }
+  // inter-pass twiddle table: per non-final pass S rows of R entries, rows padded to an even length so that every row
+  // starts on a 16-byte boundary (odd radices -- 5, 7, 3 -- in front of the last pass)
+  static constexpr int TWR(int i) { return R(i) + (R(i) & 1); }
+  static constexpr int TW_OFF(int i) { int o = 0; for (int j = 0; j < i; ++j) o += S(j) * TWR(j); return o; }
   static constexpr int TW_LANE_ELEMS = TW_OFF(NP - 1) > 0 ? TW_OFF(NP - 1) : 1;  // inter-pass twiddle rows
   static constexpr int BUF = C * FS;   // one chunk buffer (complex elements)
   static constexpr int LDS_ELEMS = BUF * (PINGPONG ? 2 : 1);
@@ -312,7 +360,6 @@ struct FastCfg {
 // MS = fused abs() with the magnitudes staged in LDS (its own instantiation of the sliding-run kernel, like CM)
 template <class K, bool CM = false, bool MS = false>
 struct FastKernel {
-  static_assert(K::R(0) % 2 == 0 && (K::NP < 3 || K::R(1) % 2 == 0), "non-final radices are even (twiddle rows are read as float4s)");
   using ST = SampleT<K::FMT>;
   using raw_t = typename ST::raw_t;
   static constexpr int M = K::M, P = K::P, D = K::D, CPT = K::CPT, C = K::C, W = K::W, OS = K::OS, NT = K::NT;
@@ -534,12 +581,12 @@ struct FastKernel {
 #pragma unroll
           for (int k = 1; k < R; ++k) x[k] = cmul_w(x[k], tw[I][k]);
         } else {
-          const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(I) + rest * R);
+          const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(I) + rest * K::TWR(I));
 #pragma unroll
-          for (int k2 = 0; k2 < R / 2; ++k2) {
+          for (int k2 = 0; k2 < K::TWR(I) / 2; ++k2) {
             const float4 t = t4[k2];
             if (k2 > 0) x[2 * k2] = cmul_w(x[2 * k2], (v2f){t.x, t.y});
-            x[2 * k2 + 1] = cmul_w(x[2 * k2 + 1], (v2f){t.z, t.w});
+            if (2 * k2 + 1 < R) x[2 * k2 + 1] = cmul_w(x[2 * k2 + 1], (v2f){t.z, t.w});
           }
         }
         const int n1 = rest / S1, rest2 = rest % S1;
@@ -748,13 +795,13 @@ struct FastKernel {
       const int R = K::R(i), S = K::S(i), IPF = M / R;
       if (C * IPF <= NT && !K::TW_TABLE) {
         const int rest = (tid % IPF) % S;
-        const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(i) + rest * R);
+        const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(i) + rest * K::TWR(i));
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) {
           if (2 * k2 < R) {
             const float4 v = t4[k2];
             k.tw[i][2 * k2] = (v2f){v.x, v.y};
-            k.tw[i][2 * k2 + 1] = (v2f){v.z, v.w};
+            k.tw[i][2 * k2 + 1] = (v2f){v.z, v.w};  // (the pad entry of an odd row: never used)
           }
         }
       }
@@ -1111,12 +1158,12 @@ struct FastKernel {
 #pragma unroll
         for (int k = 1; k < R; ++k) x[it][k] = cmul_w(x[it][k], tw[I][k]);
       } else {
-        const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(I) + (active ? rest : 0) * R);
+        const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(I) + (active ? rest : 0) * K::TWR(I));
 #pragma unroll
-        for (int k2 = 0; k2 < R / 2; ++k2) {
+        for (int k2 = 0; k2 < K::TWR(I) / 2; ++k2) {
           const float4 t = t4[k2];
           if (k2 > 0) x[it][2 * k2] = cmul_w(x[it][2 * k2], (v2f){t.x, t.y});
-          x[it][2 * k2 + 1] = cmul_w(x[it][2 * k2 + 1], (v2f){t.z, t.w});
+          if (2 * k2 + 1 < R) x[it][2 * k2 + 1] = cmul_w(x[it][2 * k2 + 1], (v2f){t.z, t.w});
         }
       }
       if (active) {
@@ -1471,7 +1518,8 @@ struct FastKernel {
 #pragma unroll
     for (int i = 0; i < K::NP - 1; ++i) {
       const int R = K::R(i), n = K::S(i) * R;
-      for (int idx = threadIdx.x; idx < n; idx += NT) twl[TWL_OFF(i) + (idx / R) * TWS(i) + idx % R] = p.tw_lane[K::TW_OFF(i) + idx];
+      for (int idx = threadIdx.x; idx < n; idx += NT)
+        twl[TWL_OFF(i) + (idx / R) * TWS(i) + idx % R] = p.tw_lane[K::TW_OFF(i) + (idx / R) * K::TWR(i) + idx % R];
     }
   }
 
@@ -2399,15 +2447,15 @@ struct SegKernel {
       if constexpr (!LAST) {
         constexpr int S1 = K::S(I + 1), RS1 = K::RS(I + 1);
         if constexpr (R % 2 == 0) {
-          const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(I) + rest * R);
+          const float4* t4 = reinterpret_cast<const float4*>(p.tw_lane + K::TW_OFF(I) + rest * K::TWR(I));
 #pragma unroll
           for (int k2 = 0; k2 < R / 2; ++k2) {
             const float4 t = t4[k2];
             if (k2 > 0) x[2 * k2] = cmul_w(x[2 * k2], (v2f){t.x, t.y});
             x[2 * k2 + 1] = cmul_w(x[2 * k2 + 1], (v2f){t.z, t.w});
           }
-        } else {  // odd radix: the table rows are not 16-byte aligned, read them element by element
-          const float2* t2 = p.tw_lane + K::TW_OFF(I) + rest * R;
+        } else {  // odd radix (rows padded to an even length): element by element
+          const float2* t2 = p.tw_lane + K::TW_OFF(I) + rest * K::TWR(I);
 #pragma unroll
           for (int k = 1; k < R; ++k) x[k] = cmul_w(x[k], (v2f){t2[k].x, t2[k].y});
         }
@@ -2537,9 +2585,10 @@ __global__ void __launch_bounds__(256) pfb_init_tables_kernel(const float* taps,
 #pragma unroll
   for (int i = 0; i < K::NP - 1; ++i) {
     const int R = K::R(i), S = K::S(i), KK = K::K(i);
-    for (int idx = threadIdx.x; idx < S * R; idx += 256) {
-      const int rest = idx / R, kk = idx % R;
-      tw_lane[K::TW_OFF(i) + idx] = tw[rest * kk * KK];
+    const int RP = K::TWR(i);
+    for (int idx = threadIdx.x; idx < S * RP; idx += 256) {
+      const int rest = idx / RP, kk = idx % RP;
+      tw_lane[K::TW_OFF(i) + idx] = kk < R ? tw[rest * kk * KK] : make_float2(0.f, 0.f);
     }
   }
 }
@@ -2624,8 +2673,13 @@ hipError_t launch_tile_t(const KernelParams& p, hipStream_t s) {
 
 // the transposed tile: single-wave two-pass plans whose chunk buffer holds the transposed chunk, rows of whole
 // 32-frame blocks
+// (the slot swizzle of tslot_frame: power-of-two chunk and lane groups)
+template <class K>
+constexpr bool kTileSlotOk = 16 % K::C == 0 && ((K::M / K::R(K::NP - 1)) >= 16 || 16 % (K::M / K::R(K::NP - 1)) == 0) &&
+                             K::C % ((K::M / K::R(K::NP - 1)) >= 16 ? 1 : 16 / (K::M / K::R(K::NP - 1))) == 0;
+
 template <class K, int NWV, int CPW>
-constexpr bool kTileTOk = K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::M * K::C <= K::LDS_ELEMS &&
+constexpr bool kTileTOk = K::NT == 64 && K::NP == 2 && !K::PINGPONG && kTileSlotOk<K> && K::M * K::C <= K::LDS_ELEMS &&
                           (NWV * CPW * K::C) % 32 == 0 && ((NWV * CPW * K::C) & (NWV * CPW * K::C - 1)) == 0 &&
                           (K::M * NWV * CPW * K::C) % (64 * NWV) == 0;
 

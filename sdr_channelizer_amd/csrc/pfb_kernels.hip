@@ -319,7 +319,7 @@ static const FastEntry kRows[] = {
 FastTablePart fast_table_m64() { return FastTablePart{kRows, (int)(sizeof(kRows) / sizeof(kRows[0]))}; }
 
 const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant, bool channel_major) {
-  const FastTablePart parts[] = {fast_table_m64(), fast_table_mid(), fast_table_big()};
+  const FastTablePart parts[] = {fast_table_m64(), fast_table_mid(), fast_table_big(), fast_table_mixed()};
   for (const FastTablePart& part : parts)
     for (int i = 0; i < part.count; ++i) {
       const FastEntry& e = part.rows[i];

@@ -1,6 +1,6 @@
-// pfb_table.h -- one row of the fused-kernel table; the table is split over three translation units
-// (pfb_kernels.hip: M = 64; pfb_kernels_mid.hip: the other single-wave shapes; pfb_kernels_big.hip: M = 1024 and
-// 560) so that they compile in parallel.
+// pfb_table.h -- one row of the fused-kernel table; the table is split over four translation units
+// (pfb_kernels.hip: M = 64; pfb_kernels_mid.hip: the other tuned single-wave shapes; pfb_kernels_big.hip: M = 1024 and
+// 560; pfb_kernels_mixed.hip: the other plausible radio rates, M = 2^a 3^b 5^c 7^d) so that they compile in parallel.
 #pragma once
 #include "pfb_fast.hpp"
 
@@ -28,5 +28,6 @@ struct FastTablePart { const FastEntry* rows; int count; };
 FastTablePart fast_table_m64();
 FastTablePart fast_table_mid();
 FastTablePart fast_table_big();
+FastTablePart fast_table_mixed();
 
 }  // namespace pfb

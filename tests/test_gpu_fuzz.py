@@ -26,6 +26,14 @@ SHAPES = [
     (10, 12, 10, ("int16",), (0,)),
     (20, 12, 20, ("int16",), (0,)),
     (40, 12, 40, ("int16",), (0,)),
+    # csrc/pfb_kernels_mixed.hip: SegKernel shapes, single-wave two-pass shapes, multi-wave three-pass shapes (lockstep / teams)
+    (12, 12, 12, ("int16",), (0,)), (24, 12, 24, ("int16",), (0,)), (25, 12, 25, ("int16",), (0,)), (30, 12, 30, ("int16",), (0,)),
+    (48, 12, 48, ("int16",), (0, 7, 11, 8)), (50, 12, 50, ("int16",), (0, 7, 11)),
+    (80, 12, 80, ("int16",), (0, 7, 11, 8)), (96, 12, 96, ("int16",), (0, 7, 11, 8)), (100, 12, 100, ("int16",), (0, 7, 11)),
+    (112, 12, 112, ("int16",), (0, 7, 11, 8)), (120, 12, 120, ("int16",), (0, 7, 11)), (160, 12, 160, ("int16",), (0,)),
+    (200, 12, 200, ("int16",), (0, 6)), (250, 12, 250, ("int16",), (0, 6)), (280, 12, 280, ("int16",), (0, 6)),
+    (320, 12, 320, ("int16",), (0, 6)), (400, 12, 400, ("int16",), (0, 6)), (500, 12, 500, ("int16",), (0, 6)),
+    (512, 12, 512, ("int16",), (0, 6)),
 ]
 
 
@@ -36,7 +44,7 @@ def make_input(rng, n, fmt):
     return synth.pulsed_iq_numpy(n, bw, np.int8 if fmt == "int8" else np.int16, seed=int(rng.integers(1 << 30))), bw
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("PFB_FUZZ_CASES", "260"))))  # 20 per shape; more with PFB_FUZZ_CASES=N
+@pytest.mark.parametrize("case", range(int(os.environ.get("PFB_FUZZ_CASES", "384"))))  # 12 per shape; more with PFB_FUZZ_CASES=N
 def test_fused_kernels_agree_with_the_generic_kernel(case):
     rng = np.random.default_rng(1000 + case)
     M, P, D, fmts, scheds = SHAPES[case % len(SHAPES)]

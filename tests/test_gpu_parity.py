@@ -30,6 +30,9 @@ def oracle_run(oracle, iq, h, M, P, D, bw, fmt="int", **kw):
 
 
 FMT_NAME = {"int8": "int8", "int16": "int16", "cf32": "cf32"}
+# band counts M = 2^a 3^b 5^c 7^d that are plausible radio rates (numBands = fs * 1e-6, channelizer_example.m:29;
+# round(fs / 0.1e6), generate_channelized_training_iq.m:95-96): the fused shapes of csrc/pfb_kernels_mixed.hip
+MIXED_RADIX_BANDS = (12, 24, 25, 30, 48, 50, 80, 96, 100, 112, 120, 160, 200, 250, 280, 320, 400, 500, 512)
 
 
 @pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "ref56", "ref560"])
@@ -60,7 +63,8 @@ def test_cfg2_uses_the_fast_kernel(golden_dir):
                                           (56, 12, 56, "int16", 12), (8, 12, 8, "int16", 12),
                                           (560, 12, 560, "int16", 12), (560, 12, 560, "int8", 8), (56, 12, 56, "int8", 8),
                                           (32, 12, 32, "int16", 12), (16, 12, 16, "int16", 12), (20, 12, 20, "int16", 12),
-                                          (10, 12, 10, "int16", 12), (40, 12, 40, "int16", 12)])
+                                          (10, 12, 10, "int16", 12), (40, 12, 40, "int16", 12)]
+                         + [(m, 12, m, "int16", 12) for m in MIXED_RADIX_BANDS])
 @pytest.mark.parametrize("q0", [0, 3])
 def test_one_hot_tap_bit_exact(M, P, D, fmt, bw, q0):
     """h = delta[n - M q0] => every channel of frame m equals x[mD + D-1 - M q0] exactly:
@@ -88,7 +92,8 @@ def test_one_hot_tap_bit_exact(M, P, D, fmt, bw, q0):
     (56, 12, 56, "int8", 8, 56 * 1500 + 3), (16, 12, 16, "int16", 12, 16 * 4000 + 9), (8, 12, 8, "int16", 12, 8 * 9000 + 3),
     (20, 12, 20, "int16", 12, 20 * 3000 + 7), (10, 12, 10, "int16", 12, 10 * 5000 + 3), (40, 12, 40, "int16", 12, 40 * 2100 + 11),
     (56, 12, 56, "cf32", 0, 56 * 1200 + 5), (128, 12, 64, "cf32", 0, (1 << 16) + 17), (256, 8, 256, "cf32", 0, (1 << 17) + 100),
-    (560, 12, 560, "cf32", 0, 560 * 130 + 77), (1024, 16, 1024, "cf32", 0, (1 << 18) + 300)])
+    (560, 12, 560, "cf32", 0, 560 * 130 + 77), (1024, 16, 1024, "cf32", 0, (1 << 18) + 300)]
+    + [(m, 12, m, "int16", 12, m * (700 if m < 100 else 260) + 11) for m in MIXED_RADIX_BANDS])
 def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     rng = np.random.default_rng(n + M)
     if fmt == "cf32":
@@ -99,14 +104,15 @@ def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=max(bw, 1)) as ch:
         y = ch(iq)
         if (M, P, D) in ((64, 12, 64), (56, 12, 56), (128, 12, 64), (256, 8, 256), (8, 12, 8), (560, 12, 560),
-                         (1024, 16, 1024)):  # fused in every format
-            assert ch.last_kernel.startswith("pfb_fast"), ch.last_kernel
+                         (1024, 16, 1024)) or (M in MIXED_RADIX_BANDS and P == 12 and D == M and fmt == "int16"):
+            assert ch.last_kernel.startswith("pfb_fast<M%d," % M), ch.last_kernel  # fused (the first group in every format)
     want = oracle_run(oracle, iq, h, M, P, D, bw, fmt)
     assert rel(y, want) < REL_TOL
 
 
 @pytest.mark.parametrize("M,P,D", [(64, 12, 64), (128, 12, 64), (56, 12, 56), (560, 12, 560), (32, 12, 32), (8, 12, 8),
-                                   (20, 12, 20), (10, 12, 10)])
+                                   (20, 12, 20), (10, 12, 10), (24, 12, 24), (25, 12, 25), (96, 12, 96), (250, 12, 250),
+                                   (320, 12, 320)])
 @pytest.mark.parametrize("kw", [dict(fftshift=True), dict(conjugate_input=True), dict(derotate=True),
                                 dict(input_offset=0), dict(input_offset=5),
                                 dict(fftshift=True, conjugate_input=True, derotate=True)])
