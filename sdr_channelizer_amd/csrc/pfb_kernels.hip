@@ -2,7 +2,8 @@
 //
 //   pfb_fast_kernel<...>   the hot path (pfb_fast.hpp), one instantiation per
 //                          (M, P, D, sample format) in kFastTable below
-//   pfb_generic_kernel     any M (2^k by radix-2 in LDS, otherwise a plain DFT),
+//   pfb_generic_kernel     any M (2^k by radix-2 in LDS, 2^a 3^b 5^c 7^d by a run-time mixed-radix
+//                          Stockham FFT, otherwise a plain DFT),
 //                          any P, any 1 <= D <= M, any format / layout: the
 //                          correctness net for configurations without a fast
 //                          instantiation (e.g. the reference's own M = fs*1e-6 = 56,
@@ -33,8 +34,12 @@ __device__ __forceinline__ void fetch_sample(const KernelParams& p, long long s,
 
 __device__ __forceinline__ int bit_reverse(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
 
+// Radices of the generic kernel's mixed-radix FFT (band counts M = 2^a 3^b 5^c 7^d that have no fused shape): at most
+// 12 stages (2^12 = 4096 = the largest M pfb_create accepts); n = 0: M has another prime factor, plain DFT.
+struct GenericPlan { int n; unsigned char r[12]; };
+
 // tile_frames frames per workgroup; sm holds tile_frames*M complex (x2 when M is not 2^k)
-__global__ void __launch_bounds__(256) pfb_generic_kernel(const KernelParams p, int tile_frames, int log2m) {
+__global__ void __launch_bounds__(256) pfb_generic_kernel(const KernelParams p, int tile_frames, int log2m, GenericPlan plan) {
   extern __shared__ float2 sm[];
   const int M = p.M, P = p.P, D = p.D;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -74,6 +79,43 @@ __global__ void __launch_bounds__(256) pfb_generic_kernel(const KernelParams p, 
         a[0] = make_float2(lo.x + br_, lo.y + bi_);
         a[half] = make_float2(lo.x - br_, lo.y - bi_);
       }
+      __syncthreads();
+    }
+  } else if (plan.n > 0) {
+    // Stockham autosort, radices 2 ... 7 at run time: O(M sum r) per frame instead of the plain DFT's O(M^2) -- 127 ms
+    // -> a few ms per 2^28 samples at M = 560.  Stage with radix r after sub-transforms of length Ns: butterfly j takes
+    // a[j + q M/r] e^{+j 2 pi q k / (Ns r)} (k = j mod Ns), an r-point DFT of those (twiddles from the M-entry table:
+    // Ns r and r divide M), and leaves u_q at (j / Ns) Ns r + k + q Ns of the other buffer: natural order at the end.
+    float2* a = sm;
+    float2* b = sm + tile_frames * M;
+    int Ns = 1;
+    for (int st = 0; st < plan.n; ++st) {
+      const int r = plan.r[st], nb = M / r, tstep = M / (Ns * r), rstep = M / r;
+      for (int idx = tid; idx < tile_frames * nb; idx += nt) {
+        const int t = idx / nb, j = idx - t * nb;
+        const int k = j % Ns;
+        float2 v[7];
+        for (int q = 0; q < r; ++q) {
+          const float2 x = a[t * M + j + q * nb], w = p.tw[(q * k * tstep) % M];
+          v[q] = make_float2(x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x);
+        }
+        float2* dst = b + t * M + (j / Ns) * Ns * r + k;
+        for (int pp = 0; pp < r; ++pp) {
+          float ur = 0.f, ui = 0.f;
+          for (int q = 0; q < r; ++q) {
+            const float2 w = p.tw[((pp * q) % r) * rstep];
+            ur += v[q].x * w.x - v[q].y * w.y;
+            ui += v[q].x * w.y + v[q].y * w.x;
+          }
+          dst[pp * Ns] = make_float2(ur, ui);
+        }
+      }
+      __syncthreads();
+      float2* sw = a; a = b; b = sw;
+      Ns *= r;
+    }
+    if (a != sm + tile_frames * M) {  // the epilogue reads the second half
+      for (int idx = tid; idx < tile_frames * M; idx += nt) sm[tile_frames * M + idx] = a[idx];
       __syncthreads();
     }
   } else {  // plain DFT into the second half of sm
@@ -139,8 +181,15 @@ hipError_t launch_generic(const KernelParams& p, hipStream_t s) {
   if (tile > 16) tile = 16;
   const size_t shmem = (size_t)tile * M * sizeof(float2) * (log2m >= 0 ? 1 : 2);
   if (shmem > 64 * 1024) return hipErrorInvalidValue;
+  GenericPlan plan{};
+  if (log2m < 0) {  // 7, 5, 3 first, then 4s and a 2: every stage length divides M by construction
+    int m = M;
+    for (int r : {7, 5, 3, 4, 2})
+      while (m % r == 0 && plan.n < 12) { plan.r[plan.n++] = (unsigned char)r; m /= r; }
+    if (m != 1) plan.n = 0;
+  }
   const long long blocks = (p.frames + tile - 1) / tile;
-  hipLaunchKernelGGL(pfb_generic_kernel, dim3((unsigned)blocks), dim3(256), shmem, s, p, tile, log2m);
+  hipLaunchKernelGGL(pfb_generic_kernel, dim3((unsigned)blocks), dim3(256), shmem, s, p, tile, log2m, plan);
   return hipGetLastError();
 }
 

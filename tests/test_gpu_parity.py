@@ -110,6 +110,20 @@ def test_random_stream_vs_oracle(oracle, M, P, D, fmt, bw, n):
     assert rel(y, want) < REL_TOL
 
 
+@pytest.mark.parametrize("M,P,D", [(6, 4, 6), (36, 12, 36), (45, 12, 45), (63, 6, 63), (75, 12, 25), (90, 12, 90), (126, 8, 63),
+                                   (360, 12, 360), (600, 12, 600), (22, 12, 22), (34, 5, 17), (121, 3, 121), (1000, 4, 1000)])
+def test_generic_kernel_any_band_count(oracle, M, P, D):
+    """Band counts without a fused shape: the generic kernel runs a run-time mixed-radix FFT (radices 2 ... 7) when
+    M = 2^a 3^b 5^c 7^d -- any other radio rate in MHz -- and a plain DFT when M has a larger prime factor (22, 34, 121)."""
+    n = D * 150 + 5
+    iq = synth.pulsed_iq_numpy(n, 12, np.int16, seed=M)
+    h = np.random.default_rng(M).standard_normal(M * P).astype(np.float32) / np.float32(M)
+    with Channelizer(M, taps=h, decimation=D, bit_width=12) as ch:
+        y = ch(iq)
+        assert ch.last_kernel == "pfb_generic"
+    assert rel(y, oracle_run(oracle, iq, h, M, P, D, 12)) < REL_TOL
+
+
 @pytest.mark.parametrize("M,P,D", [(64, 12, 64), (128, 12, 64), (56, 12, 56), (560, 12, 560), (32, 12, 32), (8, 12, 8),
                                    (20, 12, 20), (10, 12, 10), (24, 12, 24), (25, 12, 25), (96, 12, 96), (250, 12, 250),
                                    (320, 12, 320)])
