@@ -545,10 +545,12 @@ struct FastKernel {
   // vector-memory operations per step is the same on every path -- the compiler's s_waitcnt counts stay exact across
   // the chunk loop (a conditional store makes it assume the fewest, i.e. wait for MORE than the load it needs)
   // MAGSEL: -1 = PFB_FLAG_MAGNITUDE is tested here, 0 / 1 = the caller has (outside its chunk loop: same reason as FULL)
-  template <int I, bool PDW = false, bool FULL = false, int MAGSEL = -1>
+  // TWLDS: the pass's twiddle rows come from the workgroup's LDS copy `twl` (fill_twiddles) -- neither 2 R registers
+  // nor table loads that would queue behind the row prefetch
+  template <int I, bool PDW = false, bool FULL = false, int MAGSEL = -1, bool TWLDS = false>
   PFB_DEV void pass(const KernelParams& p, float2* src, float2* dst, int tid, long long f0,
                     const v2f (&tw)[2][16], float2* out_base = nullptr, long long frames_lim = -1, PdwLane* pl = nullptr,
-                    const float4* thr = nullptr, long long f_run = 0) {
+                    const float4* thr = nullptr, long long f_run = 0, const float2* twl = nullptr) {
     float2* const p_out = out_base ? out_base : p.out;
     const long long p_frames = frames_lim >= 0 ? frames_lim : p.frames;
     constexpr int R = K::R(I), S = K::S(I), KK = K::K(I), RS = K::RS(I);
@@ -577,7 +579,15 @@ struct FastKernel {
       if constexpr (!LAST) {
         constexpr int S1 = K::S(I + 1), RS1 = K::RS(I + 1);
         // twiddle e^{+j 2 pi rest k / (R S)}: row `rest` of this pass's table
-        if constexpr (TW_REGS) {
+        if constexpr (TWLDS) {
+          const float4* t4 = reinterpret_cast<const float4*>(twl + TWL_OFF(I) + rest * TWS(I));
+#pragma unroll
+          for (int k2 = 0; k2 < K::TWR(I) / 2; ++k2) {
+            const float4 t = t4[k2];
+            if (k2 > 0) x[2 * k2] = cmul_w(x[2 * k2], (v2f){t.x, t.y});
+            if (2 * k2 + 1 < R) x[2 * k2 + 1] = cmul_w(x[2 * k2 + 1], (v2f){t.z, t.w});
+          }
+        } else if constexpr (TW_REGS) {
 #pragma unroll
           for (int k = 1; k < R; ++k) x[k] = cmul_w(x[k], tw[I][k]);
         } else {
@@ -817,7 +827,7 @@ struct FastKernel {
 
   // FIR of C frames from the window x (x[i] = row f0-(W-1)+i) into LDS, then the FFT passes and the
   // stores.  u_{p_lo + D ph}[t] = sum_q h[ph + OS q] * x[row t - ph - OS q]: one v_pk_fma_f32 per tap.
-  template <bool WAVE_LOCAL = false, bool TRANSPOSED = false, bool PDW = false>
+  template <bool WAVE_LOCAL = false, bool TRANSPOSED = false, bool PDW = false, bool FULL = false, int MAGSEL = -1>
   PFB_DEV void fir_fft_store(const KernelParams& p, const Consts& k, const v2f (&x)[NW][CPT], float2* lds, int tid,
                              long long f0, PdwLane* pl = nullptr, const float4* thr = nullptr, long long f_run = 0) {
     float2* buf0 = lds;
@@ -853,11 +863,11 @@ struct FastKernel {
       last_pass_transposed(p, buf1, tid, f0);
       return;
     } else if constexpr (K::NP == 2) {
-      pass<1, PDW>(p, buf1, nullptr, tid, f0, k.tw, nullptr, -1, pl, thr, f_run);
+      pass<1, PDW, FULL, MAGSEL>(p, buf1, nullptr, tid, f0, k.tw, nullptr, -1, pl, thr, f_run);
     } else {
       pass<1>(p, buf1, buf0, tid, f0, k.tw);
       team_sync<WAVE_LOCAL>();
-      pass<2>(p, buf0, nullptr, tid, f0, k.tw);
+      pass<2, false, FULL, MAGSEL>(p, buf0, nullptr, tid, f0, k.tw);
     }
     team_sync<WAVE_LOCAL>();  // the next chunk's FIR overwrites buf0
   }
@@ -897,7 +907,10 @@ struct FastKernel {
   }
 
   // ---- schedule A: sliding window over a long contiguous run per workgroup ---------------------
-  template <bool INTERIOR, bool PDW = false>
+  // (MAGSEL / interior runs: the loop issues the same vector-memory operations on every path and is rotated -- the next
+  // chunk's rows, requested before this chunk's FIR, are taken at the END of the iteration -- so that the compiler's
+  // s_waitcnt for them counts the chunk's stores exactly instead of waiting for them too: see pass<FULL>)
+  template <bool INTERIOR, bool PDW = false, int MAGSEL = -1>
   PFB_DEV void run_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end,
                         const float4* thr = nullptr) {
     const int tid = threadIdx.x;
@@ -924,27 +937,35 @@ struct FastKernel {
     RowFetch rf;
     begin_rows<INTERIOR>(run_ptr, rf);
     load_rows<INTERIOR>(p, run_ptr, f_begin, W - 1, c0, raw, rf);
-
-    for (long long f0 = f_begin; f0 < f_end; f0 += C) {
+    auto take_rows = [&]() {
       finish_rows(c0, raw, rf);
 #pragma unroll
       for (int t = 0; t < C; ++t)
 #pragma unroll
         for (int cc = 0; cc < CPT; ++cc) x[W - 1 + t][cc] = cvt(raw[t][cc]);
-      if (f0 + C < f_end) {  // prefetch the next chunk's rows under this chunk's FFT
+    };
+    take_rows();
+    for (long long f0 = f_begin; f0 < f_end; f0 += C) {
+      if constexpr (INTERIOR && !PDW) {  // the next chunk's rows under this chunk's FFT; past the run's end: its last chunk again
+        const long long nxt = f0 + C < f_end ? f0 + C : f0;
+        load_rows<true>(p, run_ptr, nxt, (nxt - f_begin) + (W - 1), c0, raw, rf);
+      } else if (f0 + C < f_end) {
         const long long rel = (f0 - f_begin) + C + (W - 1);
         load_rows<INTERIOR>(p, run_ptr, f0 + C, rel, c0, raw, rf);
       }
-      fir_fft_store<false, false, PDW>(p, k, x, lds, tid, f0, &pl, thr, f_begin);
+      fir_fft_store<false, false, PDW, INTERIOR && !PDW, MAGSEL>(p, k, x, lds, tid, f0, &pl, thr, f_begin);
       // slide the window by C rows
 #pragma unroll
       for (int i = 0; i < W - 1; ++i)
 #pragma unroll
         for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
+      if (INTERIOR && !PDW) take_rows();
+      else if (f0 + C < f_end) take_rows();
     }
     if constexpr (PDW) pdw_finish_run(p, pl, tid, f_begin, f_end, (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0);
   }
 
+  template <int MAGSEL = -1>
   PFB_DEV void run(const KernelParams& p, float2* lds) {
     // Consecutive runs go to one XCD (blocks are dealt round-robin over the 8 XCDs, so bid%8 labels
     // the XCD).  Bijective for any grid size.
@@ -961,8 +982,8 @@ struct FastKernel {
     setup(p, threadIdx.x, k);
     // every row of the run (halo included) lies inside `in`, whole chunks only, aligned vectors
     const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_last <= p.frames);
-    if (interior) run_impl<true>(p, k, lds, f_begin, f_end);
-    else run_impl<false>(p, k, lds, f_begin, f_end);
+    if (interior) run_impl<true, false, MAGSEL>(p, k, lds, f_begin, f_end);
+    else run_impl<false, false, MAGSEL>(p, k, lds, f_begin, f_end);
   }
 
   // ---- schedule P: schedule A software-pipelined inside the wave ---------------------------------------------------
@@ -1010,9 +1031,15 @@ struct FastKernel {
     }
   }
 
-  template <bool INTERIOR, bool PDW = false>
+  // MAGSEL: PFB_FLAG_MAGNITUDE as a template parameter of the kernel, and (interior runs) unconditional stores: the
+  // number of vector-memory operations per chunk is then the same on every path, and the compiler's s_waitcnt for the
+  // rows requested two chunks ahead stops waiting for half of the previous chunk's stores as well (pass<FULL>)
+  // (tried for cfg3, whose 4 columns per lane spill 16-26 registers inside this loop: pass 0's twiddles from an LDS copy
+  // instead of 30 registers -- the spills stayed, the rate fell from 0.64 to 0.50; cfg3 went back to schedule 0)
+  static constexpr bool kOverlapTwLds = false;
+  template <bool INTERIOR, bool PDW = false, int MAGSEL = -1>
   PFB_DEV void run_overlap_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end,
-                                const float4* thr = nullptr) {
+                                const float4* thr = nullptr, const float2* twl = nullptr) {
     static_assert(NT == 64 && K::NP == 2 && !K::PINGPONG, "single-wave two-pass plans");
     PdwLane pl;
     if constexpr (PDW) {
@@ -1063,22 +1090,26 @@ struct FastKernel {
     team_sync<true>();
     float2* cur = lds;
     float2* nxt = lds + K::BUF;
+    // (the loop is rotated -- the rows requested at the top of an iteration are taken at its END -- so that a load and
+    // its wait sit in the same iteration: across the back edge the compiler merges the loop-entry state, which has no
+    // stores in flight, into its s_waitcnt count and the wait for the rows would also wait for the chunk's stores)
+    take_rows();                   // rows of chunk 1
     for (long long ci = 0; ci + 1 < nchunks; ++ci) {
-      take_rows();                 // rows of chunk ci + 1 (waits for them)
       load_chunk_rows(ci + 2);     // two chunks ahead
       // one basic block: the next chunk's FIR next to this chunk's first pass
       fir_compute(k, x, acc);
-      pass<0>(p, cur, cur, tid, f_begin + ci * C, k.tw);
+      pass<0, false, false, -1, kOverlapTwLds>(p, cur, cur, tid, f_begin + ci * C, k.tw, nullptr, -1, nullptr, nullptr, 0, twl);
       slide();
       team_sync<true>();
-      pass<1, PDW>(p, cur, nullptr, tid, f_begin + ci * C, k.tw, nullptr, -1, &pl, thr, f_begin);
+      pass<1, PDW, INTERIOR, MAGSEL>(p, cur, nullptr, tid, f_begin + ci * C, k.tw, nullptr, -1, &pl, thr, f_begin);
       fir_write(k, acc, nxt, tid);
       team_sync<true>();
       float2* t = cur; cur = nxt; nxt = t;
+      take_rows();                 // rows of chunk ci + 2 (waits for them; the chunk's stores stay in flight)
     }
-    pass<0>(p, cur, cur, tid, f_begin + (nchunks - 1) * C, k.tw);
+    pass<0, false, false, -1, kOverlapTwLds>(p, cur, cur, tid, f_begin + (nchunks - 1) * C, k.tw, nullptr, -1, nullptr, nullptr, 0, twl);
     team_sync<true>();
-    pass<1, PDW>(p, cur, nullptr, tid, f_begin + (nchunks - 1) * C, k.tw, nullptr, -1, &pl, thr, f_begin);
+    pass<1, PDW, INTERIOR, MAGSEL>(p, cur, nullptr, tid, f_begin + (nchunks - 1) * C, k.tw, nullptr, -1, &pl, thr, f_begin);
     if constexpr (PDW) pdw_finish_run(p, pl, tid, f_begin, f_end, (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0);
   }
 
@@ -1104,7 +1135,8 @@ struct FastKernel {
     else run_impl<false, true>(p, k, lds, f_begin, f_end, thr);
   }
 
-  PFB_DEV void run_overlap(const KernelParams& p, float2* lds) {
+  template <int MAGSEL = -1>
+  PFB_DEV void run_overlap(const KernelParams& p, float2* lds, float2* twl = nullptr) {
     long long run = blockIdx.x;
     if (p.xcd_remap) {
       const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
@@ -1117,8 +1149,12 @@ struct FastKernel {
     Consts k;
     setup(p, threadIdx.x, k);
     const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_last <= p.frames);
-    if (interior) run_overlap_impl<true>(p, k, lds, f_begin, f_end);
-    else run_overlap_impl<false>(p, k, lds, f_begin, f_end);
+    if constexpr (kOverlapTwLds) {
+      fill_twiddles(p, twl);
+      team_sync<true>();
+    }
+    if (interior) run_overlap_impl<true, false, MAGSEL>(p, k, lds, f_begin, f_end, nullptr, twl);
+    else run_overlap_impl<false, false, MAGSEL>(p, k, lds, f_begin, f_end, nullptr, twl);
   }
 
   // ---- schedule T: FIR team + FFT team (large M) --------------------------------------------------------
@@ -1510,7 +1546,7 @@ struct FastKernel {
   // the global table their loads would queue behind the row prefetch (a wave's vector-memory operations return in order:
   // a pass that waits for a twiddle load waits for every HBM load issued before it).  Row stride: even (16-byte reads)
   // with an odd half, so that the sixteen lanes of a ds_read_b128 group read sixteen different bank quads.
-  static constexpr int TWS(int i) { return (K::R(i) / 2) % 2 ? K::R(i) : K::R(i) + 2; }
+  static constexpr int TWS(int i) { return (K::TWR(i) / 2) % 2 ? K::TWR(i) : K::TWR(i) + 2; }
   static constexpr int TWL_OFF(int i) { int o = 0; for (int j = 0; j < i; ++j) o += K::S(j) * TWS(j); return o; }
   static constexpr int TWL_ELEMS = TWL_OFF(K::NP - 1);
 
@@ -2427,7 +2463,10 @@ struct SegKernel {
     }
   }
 
-  template <int I>
+  // FULL / MAGSEL / CMSEL: every frame exists (an interior run) and PFB_FLAG_MAGNITUDE / the output layout are template
+  // parameters of the kernel: one store per output on every path, so the compiler's s_waitcnt counts stay exact across
+  // the chunk loop (FastKernel::pass<FULL>)
+  template <int I, bool FULL = false, int MAGSEL = -1, int CMSEL = -1>
   PFB_DEV void pass(const KernelParams& p, const float2* src, float2* dst, int tid, long long f_begin, long long l_seg,
                     long long chunk0) {
     constexpr int R = K::R(I), S = K::S(I), KK = K::K(I), RS = K::RS(I);
@@ -2467,15 +2506,17 @@ struct SegKernel {
         }
       } else {
         const long long f = f_begin + (fc / C) * l_seg + chunk0 + (fc % C);  // frame (segment fc / C, chunk, t)
-        if (active && f < p.frames) {
+        if (active && (FULL || f < p.frames)) {
           const int shift = (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0;
-          const bool mag = (p.flags & PFB_FLAG_MAGNITUDE) != 0, cm = p.layout == PFB_LAYOUT_CHANNEL_MAJOR;
+          const bool mag = MAGSEL >= 0 ? MAGSEL == 1 : (p.flags & PFB_FLAG_MAGNITUDE) != 0;
+          const bool cm = CMSEL >= 0 ? CMSEL == 1 : p.layout == PFB_LAYOUT_CHANNEL_MAJOR;
 #pragma unroll
           for (int k = 0; k < R; ++k) {
             int col = kk + k * KK + shift;
             col = col >= M ? col - M : col;
             const long long o = cm ? (long long)col * p.out_ld + p.out_frame0 + f : f * M + col;
             if (mag) reinterpret_cast<float*>(p.out)[o] = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
+            else if (MAGSEL >= 0) *reinterpret_cast<v2f*>(&p.out[o]) = x[k];
             else store_c64(&p.out[o], x[k], p.nontemporal);
           }
         }
@@ -2483,7 +2524,7 @@ struct SegKernel {
     }
   }
 
-  template <bool INTERIOR>
+  template <bool INTERIOR, int MAGSEL = -1, int CMSEL = -1>
   PFB_DEV void run_impl(const KernelParams& p, float2* lds, long long f_begin, long long l_seg) {
     const int tid = threadIdx.x;
     const bool lane_on = (64 % M == 0) || tid < SEG * M;
@@ -2512,10 +2553,15 @@ struct SegKernel {
     for (int i = 0; i < W - 1; ++i) x[i] = cvt(load<INTERIOR>(p, s_row0 + (long long)i * D, f_seg - (W - 1) + i));
 #pragma unroll
     for (int t = 0; t < C; ++t) raw[t] = load<INTERIOR>(p, s_row0 + (long long)(W - 1 + t) * D, f_seg + t);
-    for (long long c0 = 0; c0 < l_seg; c0 += C) {
+    // (rotated like FastKernel::run_impl: the rows requested at the top of an iteration are taken at its end)
 #pragma unroll
-      for (int t = 0; t < C; ++t) x[W - 1 + t] = cvt(raw[t]);
-      if (c0 + C < l_seg) {
+    for (int t = 0; t < C; ++t) x[W - 1 + t] = cvt(raw[t]);
+    for (long long c0 = 0; c0 < l_seg; c0 += C) {
+      if constexpr (INTERIOR) {  // unconditional: past the segment's end its last chunk again
+        const long long cn = c0 + C < l_seg ? c0 + C : c0;
+#pragma unroll
+        for (int t = 0; t < C; ++t) raw[t] = load<true>(p, s_row0 + (cn + (W - 1) + t) * D, f_seg + cn + t);
+      } else if (c0 + C < l_seg) {
 #pragma unroll
         for (int t = 0; t < C; ++t)
           raw[t] = load<INTERIOR>(p, s_row0 + (c0 + C + (W - 1) + t) * D, f_seg + c0 + C + t);
@@ -2538,13 +2584,18 @@ struct SegKernel {
       team_sync<true>();
       pass<0>(p, buf0, buf1, tid, f_begin, l_seg, c0);
       team_sync<true>();
-      pass<1>(p, buf1, nullptr, tid, f_begin, l_seg, c0);
+      pass<1, INTERIOR, MAGSEL, CMSEL>(p, buf1, nullptr, tid, f_begin, l_seg, c0);
       team_sync<true>();
 #pragma unroll
       for (int i = 0; i < W - 1; ++i) x[i] = x[i + C];
+      if (INTERIOR || c0 + C < l_seg) {
+#pragma unroll
+        for (int t = 0; t < C; ++t) x[W - 1 + t] = cvt(raw[t]);
+      }
     }
   }
 
+  template <int MAGSEL = -1, int CMSEL = -1>
   PFB_DEV void run(const KernelParams& p, float2* lds) {
     long long run = blockIdx.x;
     if (p.xcd_remap) {
@@ -2555,22 +2606,26 @@ struct SegKernel {
     if (f_begin >= p.frames) return;
     const long long l_seg = p.frames_per_block / SEG;  // host rounds frames_per_block to a multiple of C * SEG
     const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_begin + p.frames_per_block <= p.frames);
-    if (interior) run_impl<true>(p, lds, f_begin, l_seg);
-    else run_impl<false>(p, lds, f_begin, l_seg);
+    if (interior) run_impl<true, MAGSEL, CMSEL>(p, lds, f_begin, l_seg);
+    else run_impl<false, MAGSEL, CMSEL>(p, lds, f_begin, l_seg);
   }
 };
 
-template <class K>
+template <class K, bool MAG, bool CMAJ>
 __global__ void __launch_bounds__(64, K::MIN_WAVES) pfb_seg_kernel(const KernelParams p) {
   __shared__ float2 lds[2 * SegKernel<K>::CT * K::FS];
-  SegKernel<K>::run(p, lds);
+  SegKernel<K>::template run<MAG ? 1 : 0, CMAJ ? 1 : 0>(p, lds);
 }
 
 template <class K>
 hipError_t launch_seg(const KernelParams& p, hipStream_t s) {
   if (p.frames <= 0) return hipSuccess;
   const long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
-  hipLaunchKernelGGL(pfb_seg_kernel<K>, dim3((unsigned)nb), dim3(64), 0, s, p);
+  const bool mag = (p.flags & PFB_FLAG_MAGNITUDE) != 0, cm = p.layout == PFB_LAYOUT_CHANNEL_MAJOR;
+  if (mag && cm) hipLaunchKernelGGL((pfb_seg_kernel<K, true, true>), dim3((unsigned)nb), dim3(64), 0, s, p);
+  else if (mag) hipLaunchKernelGGL((pfb_seg_kernel<K, true, false>), dim3((unsigned)nb), dim3(64), 0, s, p);
+  else if (cm) hipLaunchKernelGGL((pfb_seg_kernel<K, false, true>), dim3((unsigned)nb), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL((pfb_seg_kernel<K, false, false>), dim3((unsigned)nb), dim3(64), 0, s, p);
   return hipGetLastError();
 }
 
@@ -2614,16 +2669,18 @@ constexpr int kMagnitudeSchedule = kMagStagedOk<K> ? (K::FMT == PFB_FMT_CF32 ? 7
 template <class K>
 constexpr bool kChannelMajorOk = K::NT < 1024 && !(K::NP == 3 && K::C == 4);  // (C = 4 team plans: 32-byte runs)
 
-template <class K, bool CM = false, bool MS = false>
+// MAGSEL: -1 = PFB_FLAG_MAGNITUDE is tested inside (channel-major and staged-magnitude instantiations), 0 / 1 = decided
+// at launch (the frame-major kernels: their store count per chunk is then path-independent, see run_impl)
+template <class K, bool CM = false, bool MS = false, int MAGSEL = -1>
 __global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_fast_kernel(const KernelParams p) {
   __shared__ float2 lds[K::LDS_ELEMS];
-  FastKernel<K, CM, MS>::run(p, lds);
+  FastKernel<K, CM, MS>::template run<MAGSEL>(p, lds);
 }
 
-template <class K>
+template <class K, bool MAG>
 __global__ void __launch_bounds__(K::NT, (K::MIN_WAVES > 2 ? K::MIN_WAVES - 1 : K::MIN_WAVES)) pfb_overlap_kernel(const KernelParams p) {
-  __shared__ float2 lds[2 * K::BUF];
-  FastKernel<K>::run_overlap(p, lds);
+  __shared__ float2 lds[2 * K::BUF + (FastKernel<K>::kOverlapTwLds ? FastKernel<K>::TWL_ELEMS : 0)];
+  FastKernel<K>::template run_overlap<MAG ? 1 : 0>(p, lds, lds + 2 * K::BUF);
 }
 
 template <class K>
@@ -2934,7 +2991,8 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   if constexpr (kOverlapOk<K>) {  // sliding runs, FIR of the next chunk scheduled into the FFT of this one
     if (p.schedule == 11) {
       const long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
-      hipLaunchKernelGGL(pfb_overlap_kernel<K>, dim3((unsigned)nb), dim3(K::NT), 0, s, p);
+      if (p.flags & PFB_FLAG_MAGNITUDE) hipLaunchKernelGGL((pfb_overlap_kernel<K, true>), dim3((unsigned)nb), dim3(K::NT), 0, s, p);
+      else hipLaunchKernelGGL((pfb_overlap_kernel<K, false>), dim3((unsigned)nb), dim3(K::NT), 0, s, p);
       return hipGetLastError();
     }
   }
@@ -3025,7 +3083,8 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       return hipGetLastError();
     }
   }
-  hipLaunchKernelGGL(pfb_fast_kernel<K>, dim3((unsigned)blocks), dim3(K::NT), 0, s, p);
+  if (p.flags & PFB_FLAG_MAGNITUDE) hipLaunchKernelGGL((pfb_fast_kernel<K, false, false, 1>), dim3((unsigned)blocks), dim3(K::NT), 0, s, p);
+  else hipLaunchKernelGGL((pfb_fast_kernel<K, false, false, 0>), dim3((unsigned)blocks), dim3(K::NT), 0, s, p);
   return hipGetLastError();
 }
 

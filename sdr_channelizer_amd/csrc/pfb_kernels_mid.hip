@@ -57,9 +57,11 @@ using Cfg32x12i8seg = FastCfg<32, 12, 32, 1, PFB_FMT_INT8_IQ, 8, 2, 8, 4, 1, 4, 
 static const FastEntry kRows[] = {
     // schedule 11 (sliding runs, the next chunk's FIR scheduled into this chunk's FFT, rows two chunks ahead) over short
     // runs: cfg5 1.125 -> 1.048 ms per 2^28 samples (59.6 -> 64.0 % of roofline), cfg3 2.104 -> 2.073 ms (63.8 -> 64.8 %)
-    entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 64, 11),
-    entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 32, 11),
-    entry<Cfg256x8i16>("pfb_fast<M256,P8,D256,int16>", 32, 11),
+    entry<Cfg128x12os2i16>("pfb_fast<M128,P12,D64,int16>", 32, 11),
+    // cfg3: schedule 0 again -- once its loop kept the compiler's wait counts exact (FastKernel::run_impl) it read 0.68
+    // against 0.64 for schedule 11, whose 4-column register budget spills inside the chunk loop
+    entry<Cfg256x8i8>("pfb_fast<M256,P8,D256,int8>", 32, 0),
+    entry<Cfg256x8i16>("pfb_fast<M256,P8,D256,int16>", 32, 0),
     entry<Cfg32x12i16>("pfb_fast<M32,P12,D32,int16>", 512, 0),
     seg_entry<Cfg16x12i16>("pfb_fast<M16,P12,D16,int16>", 1024),
     seg_entry<Cfg8x12i16>("pfb_fast<M8,P12,D8,int16>", 1024),
@@ -75,7 +77,7 @@ static const FastEntry kRows[] = {
     entry<Cfg56x12i8>("pfb_fast<M56,P12,D56,int8>", 512, 7),
     entry<Cfg56x12f32>("pfb_fast<M56,P12,D56,cf32>", 512, 7),
     entry<Cfg128x12os2f32>("pfb_fast<M128,P12,D64,cf32>", 64, 0),
-    entry<Cfg256x8f32>("pfb_fast<M256,P8,D256,cf32>", 32, 11),
+    entry<Cfg256x8f32>("pfb_fast<M256,P8,D256,cf32>", 32, 0),
 };
 
 FastTablePart fast_table_mid() { return FastTablePart{kRows, (int)(sizeof(kRows) / sizeof(kRows[0]))}; }
