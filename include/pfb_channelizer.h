@@ -238,7 +238,10 @@ const char* pfb_last_error_detail(void);
 int pfb_abi_version(void);
 int pfb_device_count(void);
 
-/* ---- tuning / introspection (stable names, values may grow) ---------------- */
+/* ---- tuning / introspection (stable names, values may grow) ----------------
+ * Production knobs only.  The measurement entry points (copy-kernel yardsticks, the exception-guard self test) and the
+ * kernel-study options (PFB_OPT_GRID / TILE_WAVES / EXPERIMENT / VARIANT) live in pfb_channelizer_dev.h: same library,
+ * same pfb_set_option, not part of what an integrator binds. */
 typedef enum pfb_option {
   PFB_OPT_KERNEL = 0,           /* 0 = auto, 1 = force generic kernel, 2 = require fast kernel */
   PFB_OPT_FRAMES_PER_BLOCK = 1, /* run length per workgroup for the fast kernels (0 = default) */
@@ -247,28 +250,16 @@ typedef enum pfb_option {
   PFB_OPT_PROFILE = 4,          /* 1 = bracket every channelizer kernel launch with HIP events  */
   PFB_OPT_XCD_REMAP = 5,        /* -1 (default) = per schedule, 1 = consecutive runs stay on one XCD, */
                                 /* G > 1 = in groups of G workgroups (schedule 3), 0 = off       */
-  PFB_OPT_SCHEDULE = 6,         /* fast kernels: -1 (default) = best measured for the kernel,    */
-                                /* 0 = one sliding-window run per workgroup,                     */
-                                /* 1 = persistent waves over strided chunks, 2 = one chunk per   */
-                                /* wave with adjacent chunks grouped into workgroups, 3 = short  */
-                                /* sliding runs whose halo rows are shared through LDS, 4 = 3    */
-                                /* with the FIR and the FFT on different waves (M = 64 kernels), */
-                                /* 5 = 4 with resident workgroups walking strided tiles (int16), */
-                                /* 6 = FIR team + FFT team in one workgroup (the M = 1024 plan), */
-                                /* 7 = a FIR wave + an FFT wave per long sliding run;            */
-                                /* channel-major handles: 0 / 2 as above, 8 = short runs whose   */
-                                /* output is transposed in LDS, 9 = frame-major slabs + a        */
-                                /* transpose kernel (the default of the M = 1024 / 560 plans),   */
-                                /* 10 = the team kernel with its output tiles transposed through */
-                                /* a per-workgroup scratch (same                                 */
-                                /* M = 1024 / 560 plans: measured slower than 9, opt-in);        */
-                                /* frame-major again: 11 = 0 software-pipelined inside the wave  */
-                                /* (next chunk's FIR scheduled into this chunk's FFT; the        */
-                                /* default of M = 128 D = 64 and M = 256)                        */
-  PFB_OPT_GRID = 7,             /* schedules 1/5: workgroups to launch (0 = all that are resident) */
-  PFB_OPT_TILE_WAVES = 8,       /* schedules 2/3: waves, 4/5/7: wave pairs per workgroup         */
-  PFB_OPT_EXPERIMENT = 9,       /* bit mask of timing experiments; 0 in production               */
-  PFB_OPT_VARIANT = 10,         /* n-th fused kernel registered for this shape (0 = default plan) */
+  PFB_OPT_SCHEDULE = 6,         /* fast kernels: -1 (default) = best measured for the kernel; every schedule of a shape gives */
+                                /* the same bits.  Frame-major: 0 = one sliding-window run per workgroup, 2 = one chunk per   */
+                                /* wave with adjacent chunks grouped into workgroups, 3 = short sliding runs whose halo rows  */
+                                /* are shared through LDS, 4 = 3 with the FIR and the FFT on different waves (M = 64), 6 = a  */
+                                /* FIR team + an FFT team in one workgroup (M = 1024 / 560), 7 = a FIR wave + an FFT wave per */
+                                /* long sliding run, 11 = 0 software-pipelined inside the wave (M = 128 D = 64), 13 = several */
+                                /* independent few-wave workgroups per CU (a variant of M = 1024).  Channel-major handles:    */
+                                /* 0 / 2 as above, 8 = short runs whose output is transposed in LDS, 9 = frame-major slabs +  */
+                                /* a transpose kernel (the default of the M = 1024 / 560 plans).  1, 5, 10, 12: removed.      */
+  /* 7 ... 10: pfb_channelizer_dev.h */
   PFB_OPT_SLAB_FRAMES = 11      /* channel-major by slabs (schedule 9): frames per slab, 0 = one run per CU */
 } pfb_option;
 int pfb_set_option(pfb_handle* h, int option, int64_t value);
@@ -280,28 +271,8 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value);
 int pfb_get_kernel_times(pfb_handle* h, float* ms_out, int capacity, int* count);
 /* Name of the kernel the last process call launched ("" before the first). */
 const char* pfb_last_kernel(const pfb_handle* h);
-/* Device stream-copy (read 1 : write 2, like cfg 2's traffic) timed with HIP
- * events: bytes moved per second, for the "measured peak" next to the nominal
- * roofline.  Uses `bytes_in` of input and 2*bytes_in of output scratch.  The kernel is the
- * fastest 1:2 shape tools/membench2 found on MI355X (short-lived 4-wave workgroups, two 256-byte
- * rows per wave, one 16-byte store per lane), so the figure is a yardstick no channelizer kernel
- * with this byte mix should beat. */
-int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double* bytes_per_sec);
-/* The same for either byte mix of the channelizer and a given wave lifetime: a copy kernel with no arithmetic that
- * reads bytes_in and writes write_ratio x bytes_in (2: int16 I/Q -> complex64 at D = M; 4: int8 I/Q, or int16 at D = M/2),
- * every wave owning rows_per_wave consecutive 256-byte rows (even, >= 2).  What the memory system gives that byte mix
- * depends on how short-lived the waves are (0.78 / 0.75 of the nominal 8 TB/s at 2 rows, 0.63 / 0.64 at 512): the
- * bound bench.py prints next to each shape's fraction. */
-/* Timing probe of the fused PDW screen (schedule 12 -- not selectable through PFB_OPT_SCHEDULE, it needs the screen's tables; measured slower than the
- * separate bracket pass) with
- * caller-made thresholds: thr4 = M x (below-bracket, above-bracket, under-threshold, over-threshold) float32 limits on
- * |y|^2, host memory.  Device buffers; frames must be a multiple of 64.  counters[3]: candidates parked, samples
- * listed as undecided, flags.  Shapes without the fused instantiation: PFB_ERR_UNSUPPORTED. */
-int pfb_probe_pdw_fused(pfb_handle* handle, const void* d_iq, uint64_t num_samples, void* d_out, uint64_t capacity_frames,
-                        const float* thr4, int iters, double* ms_per_call, uint64_t* counters);
-
-int pfb_measure_mix_copy(int device_id, uint64_t bytes_in, uint32_t write_ratio, uint32_t rows_per_wave, int iters,
-                         double* bytes_per_sec);
+/* The device the handle lives on (pfb_config.device_id resolved: -1 became the device current at pfb_create). */
+int pfb_get_device(const pfb_handle* h, int* device_id);
 
 /* Page-locked host memory for the sample and output buffers of PFB_MEM_HOST calls -- what the
  * recorders would use in place of `new std::complex<std::int16_t>[n]`
@@ -310,10 +281,6 @@ int pfb_measure_mix_copy(int device_id, uint64_t bytes_in, uint32_t write_ratio,
  * really overlap (pageable memory works, at the rate of the runtime's own staging).  NULL on failure. */
 void* pfb_host_alloc(size_t bytes);
 void pfb_host_free(void* p);
-/* Diagnostic: throws a C++ exception of the given kind (0 = std::bad_alloc, 1 = std::runtime_error,
- * 2 = a non-std type) INSIDE the guard every entry point runs under and returns what the guard
- * returns (PFB_ERR_NO_MEMORY / PFB_ERR_INTERNAL): proof that nothing thrown crosses the C ABI. */
-int pfb_selftest_exception_guard(int kind);
 
 /* ---- channelized PDW extraction ------------------------------------------------
  * Replaces the second half of matlab/create_pdws_channelized.m (lines 64-143): per-channel

@@ -78,17 +78,19 @@ class PfbIqInfo(C.Structure):
     ]
 
 
-# every symbol include/pfb_channelizer.h + include/pfb_iq_packet.h declare
+# every symbol include/pfb_channelizer.h + include/pfb_iq_packet.h declare: the drop-in boundary
 EXPORTS = (
     "pfb_create", "pfb_destroy", "pfb_reset", "pfb_set_stream", "pfb_process", "pfb_process_async", "pfb_sync", "pfb_process_iq_file",
     "pfb_frames_for", "pfb_history_samples", "pfb_prime", "pfb_get_state", "pfb_set_state", "pfb_set_frame_index",
     "pfb_get_frame_index", "pfb_center_frequencies", "pfb_design_prototype", "pfb_strerror",
-    "pfb_last_error_detail", "pfb_abi_version", "pfb_device_count", "pfb_set_option", "pfb_last_kernel",
-    "pfb_measure_stream_copy", "pfb_get_kernel_times", "pfb_host_alloc", "pfb_host_free", "pfb_pdw_extract", "pfb_pdw_extract_raw", "pfb_pdw_from_iq_file", "pfb_pdw_raw_from_iq_file", "pfb_pdw_last_error_detail", "pfb_pdw_release_workspace", "pfb_pdw_last_noise_floor_path",
+    "pfb_last_error_detail", "pfb_abi_version", "pfb_device_count", "pfb_set_option", "pfb_last_kernel", "pfb_get_device",
+    "pfb_get_kernel_times", "pfb_host_alloc", "pfb_host_free", "pfb_pdw_extract", "pfb_pdw_extract_raw", "pfb_pdw_from_iq_file", "pfb_pdw_raw_from_iq_file", "pfb_pdw_last_error_detail", "pfb_pdw_release_workspace", "pfb_pdw_last_noise_floor_path",
     "pfb_iq_parse_header", "pfb_iq_fill_packet", "pfb_iq_filename",
     "pfb_shard_attach", "pfb_halo_samples", "pfb_shard_head_frames", "pfb_halo_recv_buffer", "pfb_process_shard_async",
-    "pfb_center_frequencies_ordered", "pfb_selftest_exception_guard", "pfb_measure_mix_copy", "pfb_probe_pdw_fused",
+    "pfb_center_frequencies_ordered",
 )
+# include/pfb_channelizer_dev.h: measurement yardsticks and the ABI self test (bench.py, tools/, tests/)
+DEV_EXPORTS = ("pfb_measure_stream_copy", "pfb_measure_mix_copy", "pfb_selftest_exception_guard")
 
 _lib = None
 
@@ -154,6 +156,7 @@ def load() -> C.CDLL:
     lib.pfb_set_option.argtypes = [vp, C.c_int, i64]
     lib.pfb_last_kernel.argtypes = [vp]
     lib.pfb_last_kernel.restype = C.c_char_p
+    lib.pfb_get_device.argtypes = [vp, C.POINTER(C.c_int)]
     lib.pfb_get_kernel_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     lib.pfb_host_alloc.argtypes = [C.c_size_t]
     lib.pfb_host_alloc.restype = C.c_void_p
@@ -175,17 +178,13 @@ def load() -> C.CDLL:
     lib.pfb_pdw_last_noise_floor_path.restype = C.c_int
     lib.pfb_measure_stream_copy.argtypes = [C.c_int, u64, C.c_int, C.POINTER(C.c_double)]
     lib.pfb_measure_mix_copy.argtypes = [C.c_int, u64, u32, u32, C.c_int, C.POINTER(C.c_double)]
-    lib.pfb_probe_pdw_fused.argtypes = [C.c_void_p, C.c_void_p, u64, C.c_void_p, u64, C.POINTER(C.c_float), C.c_int,
-                                        C.POINTER(C.c_double), C.POINTER(u64)]
     lib.pfb_iq_parse_header.argtypes = [vp, C.c_size_t, C.POINTER(PfbIqInfo)]
     lib.pfb_iq_fill_packet.argtypes = [C.POINTER(PfbIqPacket), u32, u64, u32, u32, C.c_float, u32, u32,
                                        C.c_char_p, C.c_char_p, C.c_double]
     lib.pfb_iq_fill_packet.restype = None
     lib.pfb_iq_filename.argtypes = [i64, C.c_char_p, C.c_int]
-    for name in EXPORTS:
-        f = getattr(lib, name)  # AttributeError here = header/library mismatch
-        if f.restype is C.c_int and name not in ("pfb_strerror",):
-            pass
+    for name in EXPORTS + DEV_EXPORTS:
+        getattr(lib, name)  # AttributeError here = header/library mismatch
     _lib = lib
     return lib
 

@@ -18,6 +18,7 @@ LIB = os.path.join(PKG, "libpfb_channelizer.so")
 SOURCES = ["pfb_api.cpp", "pfb_kernels.hip", "pfb_kernels_mid.hip", "pfb_kernels_big.hip", "pfb_kernels_mixed.hip", "pfb_pdw.hip", "iq_packet.c"]
 HEADERS = ["pfb_common.h", "pfb_fast.hpp", "pfb_table.h"]
 ARCH = "gfx950"
+PUBLIC_HEADERS = ["pfb_channelizer.h", "pfb_channelizer_dev.h", "pfb_iq_packet.h"]
 
 
 def _hipcc() -> str:
@@ -32,7 +33,7 @@ def needs_build() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    deps += [os.path.join(ROOT, "include", f) for f in ("pfb_channelizer.h", "pfb_iq_packet.h")]
+    deps += [os.path.join(ROOT, "include", f) for f in PUBLIC_HEADERS]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -45,15 +46,19 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(bdir, exist_ok=True)
     common = ["-O3", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
     jobs = []
+    hdr_time = max(os.path.getmtime(h) for h in [os.path.join(CSRC, f) for f in HEADERS] +
+                   [os.path.join(ROOT, "include", f) for f in PUBLIC_HEADERS])
     for src in SOURCES:
         obj = os.path.join(bdir, src + ".o")
         path = os.path.join(CSRC, src)
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
+            continue  # this translation unit is up to date
         if src.endswith(".c"):
             cmd = [hipcc, "-x", "c", "-std=c11"] + common + ["-c", path, "-o", obj]
         else:
             cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-std=c++20"] + common + ["-c", path, "-o", obj]
         jobs.append(cmd)
-        objs.append(obj)
 
     def compile_one(cmd):
         if verbose:

@@ -102,11 +102,9 @@ class Channelizer:
                           int(input_offset), int(device))
         L.check(lib.pfb_create(C.byref(cfg), C.byref(self._h)), "pfb_create")
         self._lib = lib
-        if device >= 0:
-            self._device_index = int(device)
-        else:  # the library took the current device; ask torch (same runtime) which one that was
-            import torch
-            self._device_index = int(torch.cuda.current_device())
+        dev = C.c_int(-1)  # device=-1: the library took the device current at pfb_create; it says which one that was
+        L.check(lib.pfb_get_device(self._h, C.byref(dev)), "pfb_get_device")
+        self._device_index = int(dev.value)
 
     # -- lifecycle ---------------------------------------------------------------
     def release(self) -> None:

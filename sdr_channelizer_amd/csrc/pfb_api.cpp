@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "pfb_common.h"
+#include "pfb_channelizer_dev.h"
 
 namespace {
 
@@ -64,7 +65,6 @@ struct StateHeader {
 }  // namespace
 
 struct pfb_handle {
-  const pfb::PdwFuse* pdw_fuse = nullptr;  // set while a fused channelize + PDW screen call is running (schedule 12)
   int M = 0, P = 0, D = 0, off = 0;
   int fmt = 0, bit_width = 0, layout = 0;
   unsigned flags = 0;
@@ -95,7 +95,7 @@ struct pfb_handle {
   int opt_grid = 0;
   int opt_tile_waves = 8;
   int64_t opt_slab_frames = 0;  // channel-major by slabs: frames per slab (0 = ~32 MiB of output)
-  void* d_slab = nullptr;       // frame-major scratch of the slab path (and the tiles of schedule 10)
+  void* d_slab = nullptr;       // frame-major scratch of the slab path
   size_t slab_bytes = 0;
   void* d_matrix = nullptr;     // pfb_pdw_from_iq_file: the record's channel matrix (grow-only)
   size_t matrix_bytes = 0;
@@ -222,12 +222,9 @@ int launch_frames(pfb_handle* h, const void* d_iq, uint64_t n, const void* hist,
   // any shape, PFB_OPT_SLAB_FRAMES sets their length.
   const bool cm = h->layout == PFB_LAYOUT_CHANNEL_MAJOR;
   const bool forced_fused = h->opt_schedule == 0 || h->opt_schedule == 2 || h->opt_schedule == 8;
-  // Team plans also have a fused route (schedule 10): the frame-major kernel itself, resident workgroups, each writing
-  // tiles of cm_tile_frames frames into its own scratch slot (rewritten every other tile) and its FFT waves transposing
-  // them into place -- no slab, no second kernel.  Bit-identical, but slower than the slabs.
-  const bool by_tiles = cm && want_fast && h->fast->cm_tile_frames > 0 && !(h->flags & PFB_FLAG_MAGNITUDE) &&
-                        h->opt_schedule == 10;  // measured SLOWER than the slabs (7.4 vs 6.4 ms per 2^30 at M = 1024): opt-in only
-  const bool by_slabs = cm && want_fast && !by_tiles && (!h->fast->channel_major_ok || h->opt_schedule == 9);
+  // (A fused route for the team plans -- the team kernel transposing its own tiles through an L2-resident scratch -- was
+  // bit-identical but slower than the slabs, 7.4 against 6.4 ms per 2^30 samples at M = 1024, and was removed.)
+  const bool by_slabs = cm && want_fast && (!h->fast->channel_major_ok || h->opt_schedule == 9);
   if (want_fast) {
     const int c = h->fast->chunk_frames;
     int fpb = h->opt_frames_per_block > 0 ? h->opt_frames_per_block : h->fast->default_frames_per_block;
@@ -238,36 +235,14 @@ int launch_frames(pfb_handle* h, const void* d_iq, uint64_t n, const void* hist,
     }
     if (cm && !by_slabs)  // fused channel-major: 0 = sliding runs, 2 = tiles, 8 = short runs transposed in LDS, else the kernel's pick
       p.schedule = forced_fused ? h->opt_schedule : -1;
-    if (by_tiles) p.schedule = 10;
-    if (h->pdw_fuse) {  // the PDW screen rides in the last pass: runs of exactly one 64-frame mask word
-      if (cm || !h->fast->pdw_fused_ok) return PFB_ERR_UNSUPPORTED;
-      p.schedule = 12;
-      p.pdw = h->pdw_fuse;
-      fpb = 64;
-      if (h->opt_xcd_remap < 0) p.xcd_remap = 0;
-    }
     if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
     if (p.schedule == 6 || p.schedule == 7) fpb = ((fpb + 2 * c - 1) / (2 * c)) * (2 * c);  // these kernels walk chunks in pairs
-    if (p.schedule == 4 || p.schedule == 5) {
+    if (p.schedule == 4) {
       if (h->opt_frames_per_block <= 0) fpb = 64;
       if (h->opt_xcd_remap < 0) p.xcd_remap = 0;  // 512-frame workgroups: one dense sweep beats L2 halo hits
     }
     // short sliding runs in dispatch order already sweep the stream as one window: leave them round-robin over the XCDs
     if ((p.schedule == 0 || p.schedule == 11) && fpb <= 64 && h->opt_xcd_remap < 0) p.xcd_remap = 0;
-    if (by_tiles) {
-      fpb = std::max(32, (fpb + 31) / 32 * 32);  // whole tiles (of 32 or 16 frames), chunks in pairs
-      const int slots = h->num_cus;              // one workgroup per CU is resident (LDS); the launcher clamps its grid
-      const size_t need = (size_t)slots * 2 * h->fast->cm_tile_frames * h->M * sizeof(float2);  // two tiles per slot
-      if (need > h->slab_bytes) {
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        (void)hipFree(h->d_slab);
-        h->d_slab = nullptr; h->slab_bytes = 0;
-        HIP_TRY(hipMalloc(&h->d_slab, need));
-        h->slab_bytes = need;
-      }
-      p.scratch = h->d_slab;
-      p.scratch_slots = slots;
-    }
     p.frames_per_block = fpb;
     const int cpt = h->fast->cols_per_thread;
     const int bmod = ((p.base % cpt) + cpt) % cpt;
@@ -1137,7 +1112,7 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_nontemporal = value ? 1 : 0;
       return PFB_OK;
     case PFB_OPT_SCHEDULE:
-      if (value < -1 || value > 13 || value == 12) return PFB_ERR_BAD_ARG;
+      if (value < -1 || value > 13 || value == 1 || value == 5 || value == 10 || value == 12) return PFB_ERR_BAD_ARG;  // (removed studies)
       h->opt_schedule = (int)value;
       return PFB_OK;
     case PFB_OPT_TILE_WAVES:
@@ -1153,9 +1128,8 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
       h->opt_xcd_remap = (int)value;
       return PFB_OK;
     case PFB_OPT_EXPERIMENT:
+      if (value < 0 || value > 0xffff) return PFB_ERR_BAD_ARG;
       h->opt_experiment = (int)value;
-      pfb::g_transpose_probe = (int)((value >> 16) & 3);
-      if (((value >> 20) & 0xfff) != 0) pfb::g_transpose_tile_frames = (int)((value >> 20) & 0xfff);  // tuning: slab transposer tile
       return PFB_OK;
     case PFB_OPT_SLAB_FRAMES:
       if (value < 0 || value > (1ll << 32)) return PFB_ERR_BAD_ARG;
@@ -1199,6 +1173,12 @@ int pfb_set_option(pfb_handle* h, int option, int64_t value) {
 }
 
 const char* pfb_last_kernel(const pfb_handle* h) { return h ? h->last_kernel : ""; }
+
+int pfb_get_device(const pfb_handle* h, int* device_id) {
+  if (!h || !device_id) return PFB_ERR_BAD_ARG;
+  *device_id = h->device;
+  return PFB_OK;
+}
 
 int pfb_get_kernel_times(pfb_handle* h, float* ms_out, int capacity, int* count) {
   return pfb::abi_guard([&]() -> int {
@@ -1260,76 +1240,6 @@ int pfb_measure_stream_copy(int device_id, uint64_t bytes_in, int iters, double*
   if (e1) (void)hipEventDestroy(e1);
   (void)hipFree(in);
   (void)hipFree(out);
-  return rc;
-  });
-}
-
-// Timing probe of the fused screen (schedule 12) with caller-made thresholds: thr4 = M x (a, b, c, d) float32 on the
-// host.  counters: [0] candidates parked, [1] undecided listed, [2] flags.  Buffers live for the call only.
-int pfb_probe_pdw_fused(pfb_handle* h, const void* d_iq, uint64_t n, void* d_out, uint64_t cap_frames, const float* thr4,
-                        int iters, double* ms, uint64_t* counters) {
-  return pfb::abi_guard([&]() -> int {
-  if (!h || !d_iq || !d_out || !thr4 || !ms || iters < 1) return PFB_ERR_BAD_ARG;
-  if (!h->fast || !h->fast->pdw_fused_ok) return PFB_ERR_UNSUPPORTED;
-  DeviceGuard g(h->device);
-  const uint64_t F = frames_for(h, n);
-  if (F > cap_frames || F % 64) return PFB_ERR_BAD_ARG;
-  const uint64_t runs = F / 64;
-  const int cap = 384, und_cap = 1 << 20;
-  pfb::PdwFuse f{};
-  char* blob = nullptr;
-  auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
-  const size_t sz[] = {pad((size_t)h->M * 16), pad(runs * cap * 8), pad(runs * cap * 2), pad(runs * 4), pad(runs * h->M * 8),
-                       pad(runs * h->M * 8), pad(runs * h->M), pad((size_t)und_cap * 8), 256, 256, pad(sizeof(pfb::PdwFuse))};
-  size_t total = 0;
-  for (size_t b : sz) total += b;
-  HIP_TRY(hipMalloc((void**)&blob, total));
-  size_t o = 0;
-  auto take = [&](int i) { char* r = blob + o; o += sz[i]; return r; };
-  float4* d_thr = (float4*)take(0);
-  f.thr = d_thr;
-  f.cand_v = (float2*)take(1); f.cand_c = (unsigned short*)take(2); f.cand_n = (unsigned*)take(3);
-  f.f0 = (unsigned long long*)take(4); f.f1 = (unsigned long long*)take(5); f.below_run = (unsigned char*)take(6);
-  f.undecided = (unsigned long long*)take(7); f.und_n = (unsigned*)take(8); f.flags = (unsigned*)take(9);
-  pfb::PdwFuse* d_f = (pfb::PdwFuse*)take(10);
-  f.cap = cap; f.und_cap = und_cap;
-  int rc = PFB_OK;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  float t = 0.f;
-  std::vector<unsigned> h_n;
-  hipError_t e = hipMemcpy(d_thr, thr4, (size_t)h->M * 16, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_f, &f, sizeof(f), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipEventCreate(&e0);
-  if (e == hipSuccess) e = hipEventCreate(&e1);
-  if (e != hipSuccess) { rc = hip_fail(e, "pfb_probe_pdw_fused setup"); goto out; }
-  h->pdw_fuse = d_f;
-  for (int it = -2; it < iters && rc == PFB_OK; ++it) {
-    if (it == 0) (void)hipEventRecord(e0, h->stream);
-    (void)hipMemsetAsync(f.und_n, 0, 512, h->stream);  // und_n and flags
-    pfb_reset(h);
-    rc = enqueue(h, d_iq, n, d_out, F, (int64_t)F, 0);
-  }
-  h->pdw_fuse = nullptr;
-  (void)hipEventRecord(e1, h->stream);
-  (void)hipStreamSynchronize(h->stream);
-  if (rc == PFB_OK) {
-    (void)hipEventElapsedTime(&t, e0, e1);
-    *ms = (double)t / iters;
-    if (counters) {
-      h_n.resize(runs);
-      unsigned un = 0, fl = 0;
-      (void)hipMemcpy(h_n.data(), f.cand_n, runs * 4, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(&un, f.und_n, 4, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(&fl, f.flags, 4, hipMemcpyDeviceToHost);
-      uint64_t tot = 0;
-      for (unsigned v : h_n) tot += v;
-      counters[0] = tot; counters[1] = un; counters[2] = fl;
-    }
-  }
-out:
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
-  (void)hipFree(blob);
   return rc;
   });
 }

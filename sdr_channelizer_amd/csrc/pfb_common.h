@@ -29,22 +29,6 @@ static inline int abi_guard(F&& body) noexcept {
 //   sample index of (row r, column c) = r*D + base + c,   c = 0..D-1
 // relative to in[0]; negative indices live in the history buffer, whose last
 // element hist[hist_samples-1] is the sample just before in[0].
-// PDW extraction fused into the channelizer's last pass (pfb_overlap_pdw_kernel; the consumer is pfb_pdw.hip): where the
-// float32 screens of every output column live and where a run's findings go.  Device-resident, one per extraction.
-struct PdwFuse {
-  const float4* thr;             // [M] per OUTPUT column: (below the bracket if <, above it if >, under the threshold if <, over it if >)
-  float2* cand_v;                // [runs][cap] samples inside the bracket's zone, as stored
-  unsigned short* cand_c;        // [runs][cap] their columns
-  unsigned* cand_n;              // [runs] how many (may exceed cap: the run overflowed, flags |= 1)
-  unsigned long long* f0;        // [words][M] provisional comparison masks, one word per run and column
-  unsigned long long* f1;
-  unsigned char* below_run;      // [runs][M] samples surely below the bracket
-  unsigned long long* undecided; // samples inside the threshold's band: frame * M + column
-  unsigned* und_n;
-  unsigned* flags;               // 1: a run's list overflowed, 4: the undecided list overflowed
-  int cap, und_cap;
-};
-
 struct KernelParams {
   const void* in;          // this call's samples (device), cfg.sample_format
   const void* hist;        // hist_samples samples of history (device)
@@ -69,13 +53,9 @@ struct KernelParams {
   int nontemporal;         // nontemporal output stores
   int xcd_remap;           // fast kernels: 1 = consecutive runs on one XCD, G>1 = in groups of G
   int experiment;          // bit mask of timing experiments (0 in production)
-  int schedule;            // fast kernels: 0 = sliding-window runs, 1 = persistent strided chunks,
-                           //               2 = one chunk per wave, tile_waves chunks per workgroup
-  int tile_waves;          // schedule 2: waves (= adjacent chunks) per workgroup: 1, 2, 4, 8 or 16
-  int grid_override;       // schedule 1: workgroups to launch (0 = what is resident at once)
-  void* scratch;           // schedule 10: scratch_slots x 2 tiles of cm_tile_frames x M complex64, a slot per resident workgroup
-  int scratch_slots;
-  const PdwFuse* pdw;      // pfb_overlap_pdw_kernel only
+  int schedule;            // fast kernels: the list at the top of pfb_fast.hpp
+  int tile_waves;          // schedules 2 / 3 / 8: waves, 4 / 7: wave pairs per workgroup
+  int grid_override;       // schedule 13: workgroups to launch, each walking runs b, b + G, ... (0 = one per run)
 };
 
 // sample traits -----------------------------------------------------------------
@@ -125,8 +105,6 @@ struct FastKernelInfo {
   int default_schedule;    // measured best schedule for this instantiation (PFB_OPT_SCHEDULE = -1)
   bool channel_major_ok;   // has a channel-major instantiation
   int magnitude_schedule;  // measured best schedule with PFB_FLAG_MAGNITUDE, -1 = default_schedule
-  int cm_tile_frames;      // > 0: the team kernel has a fused channel-major route (schedule 10) with tiles of this many frames
-  bool pdw_fused_ok;       // has the instantiation with the PDW screen in its last pass (schedule 12)
 };
 const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant = 0, bool channel_major = false);
 
@@ -137,7 +115,5 @@ hipError_t launch_transpose_slab(const void* slab, long long frames, int M, void
                                  long long out_frame0, int elem_bytes, hipStream_t s);
 hipError_t launch_stream_copy(const void* in, void* out, long long n_vec16, hipStream_t s);
 hipError_t launch_mix_copy(const void* in, void* out, long long rows, int write_ratio, int spw, hipStream_t s);
-extern int g_transpose_probe;
-extern int g_transpose_tile_frames;  // frames per tile of the slab transposer: 64, 128 or 256
 
 }  // namespace pfb

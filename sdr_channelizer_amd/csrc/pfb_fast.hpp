@@ -30,21 +30,22 @@
 //
 // The arithmetic above is shared by several SCHEDULES (who computes which frames
 // when; PFB_OPT_SCHEDULE, bit-identical outputs per shape):
-//   0 (A)  one sliding run per workgroup, FIR and FFT by the same threads
-//   1 (B)  persistent workgroups over strided chunks          (access-shape study)
+//   0 (A)  one sliding run per workgroup, FIR and FFT by the same threads   (M = 256, small and mixed-radix banks)
 //   2 (C)  one chunk per wave, adjacent chunks per workgroup  (access-shape study; channel-major fallback)
 //   3 (D)  short runs whose halo rows are shared through LDS
 //   4 (F)  D with a FIR wave and an FFT wave per run          (M = 64 default)
-//   5 (G)  F with resident workgroups, halo prefetched HBM -> LDS
 //   6 (T)  a FIR team and an FFT team per workgroup           (M = 1024 / 560 default)
 //   7 (H)  a FIR wave and an FFT wave per long sliding run    (M = 56 default)
 //   8 (C') channel-major only: short sliding runs, each chunk transposed in its LDS buffer, the workgroup's
 //          tile written as 256-512-byte runs per channel       (channel-major default of the single-wave plans)
 //   9      channel-major only, host side (pfb_api.cpp): frame-major slabs + pfb_transpose_slab_kernel
-//  10 (T') channel-major only: T with resident workgroups whose FFT waves transpose finished 32-frame tiles out of a
-//          per-workgroup scratch (bit-identical, slower than 9: opt-in)
 //  11 (P)  A software-pipelined inside the wave: next chunk's FIR next to this chunk's first FFT pass, two LDS chunk
-//          buffers, rows two chunks ahead                      (cfg5 / M = 256 default)
+//          buffers, rows two chunks ahead                      (M = 128 D = 64 default)
+//  13 (W)  independent workgroups of a few waves, a frame per wave and chunk, all passes of a frame by one wave
+//          (variant 3 of M = 1024 int16)
+// Numbers 1, 5, 10 and 12 were studies that lost to the above (persistent strided chunks, persistent wave pairs, the team
+// kernel transposing through scratch tiles, the PDW screen fused into the last pass); their measurements are in
+// DESIGN.md sections 5 and 9, their code is gone.
 #pragma once
 
 #include "pfb_common.h"
@@ -466,93 +467,15 @@ struct FastKernel {
     }
   }
 
-  // out_base / frames_lim: the last pass's destination when it is not p.out (the team kernel's scratch tile)
-  // ---- PDW screen fused into the last pass (pfb_overlap_pdw_kernel) ----------------------------------------------
-  // A run of this kernel is 64 frames = one comparison-mask word per column.  Lane (g = tid / IPF, kk = tid % IPF)
-  // sees frames g + C/2... of every chunk for its R columns kk + k KK: per column 16 of the word's 64 frames, bit
-  // j = (frame in run) / 4 of a 16-bit field; the four lane groups are interleaved into the word when the run ends.
-  struct PdwLane {
-    unsigned ov[4];    // "surely over the threshold" bits, two columns per register
-    unsigned nb[2];    // "surely below the bracket" counts, 8-bit fields, four columns per register
-    unsigned cnt;      // entries this run has appended to its candidate list (uniform over the wave)
-    int run;           // run index = word index
-  };
-  static constexpr bool kPdwOk = NT == 64 && K::NP == 2 && !K::PINGPONG && K::POW2 && K::R(K::NP - 1) == 8 &&
-                                 M / K::R(K::NP - 1) == 16 && C == 8 && M <= 65535 && K::FMT != PFB_FMT_CF32;
-
-  PFB_DEV void pdw_visit(const KernelParams& p, PdwLane& pl, const float4* thr, v2f v, int k, int col, int j, long long f) {
-    const PdwFuse& q = *p.pdw;
-    const float m32 = __builtin_fmaf(v.x, v.x, v.y * v.y);
-    const float4 t = thr[col];
-    pl.nb[k >> 2] += (unsigned)(m32 < t.x) << (8 * (k & 3));
-    const bool zone = !(m32 < t.x) && !(m32 > t.y);
-    const unsigned long long bal = __ballot(zone);
-    if (bal) {  // park the sample, as stored, in the run's list: slots by ballot, no atomics
-      const unsigned pos = pl.cnt + (unsigned)__popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull));
-      if (zone && pos < (unsigned)q.cap) {
-        const unsigned at = (unsigned)pl.run * (unsigned)q.cap + pos;  // runs * cap < 2^32 (checked by the host)
-        q.cand_v[at] = make_float2(v.x, v.y);
-        q.cand_c[at] = (unsigned short)col;
-      }
-      pl.cnt += (unsigned)__popcll(bal);
-    }
-    pl.ov[k >> 1] |= (unsigned)(m32 > t.w) << (j + 16 * (k & 1));
-    const bool band = !(m32 < t.z) && !(m32 > t.w);
-    if (__ballot(band)) {  // inside the threshold's zone (a handful per record): listed, classified exactly once the median is known
-      if (band) {
-        const unsigned u = atomicAdd(q.und_n, 1u);
-        if (u < (unsigned)q.und_cap) q.undecided[u] = (unsigned long long)f * (unsigned long long)M + (unsigned)col;
-        else atomicOr(q.flags, 4u);
-      }
-    }
-  }
-
-  // the run is over: interleave the four lane groups' 16-bit fields into the word of every column, add up the counts
-  PFB_DEV void pdw_finish_run(const KernelParams& p, const PdwLane& pl, int tid, long long f_begin, long long f_end, int shift) {
-    const PdwFuse& q = *p.pdw;
-    constexpr int R = K::R(K::NP - 1), KK = K::K(K::NP - 1), IPF = M / R;
-    const int g = tid / IPF, kk = tid % IPF;
-    const long long nfr = f_end - f_begin;
-    const unsigned long long pad = nfr >= 64 ? 0ull : ~0ull << nfr;  // frames past the end: identity (f0 = 0, f1 = 1)
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-      unsigned long long x = (pl.ov[k >> 1] >> (16 * (k & 1))) & 0xffffu;  // bit j -> bit 4 j + g
-      x = (x | (x << 24)) & 0x000000FF000000FFull;
-      x = (x | (x << 12)) & 0x000F000F000F000Full;
-      x = (x | (x << 6)) & 0x0303030303030303ull;
-      x = (x | (x << 3)) & 0x1111111111111111ull;
-      x <<= g;
-      x |= __shfl_xor(x, IPF);
-      x |= __shfl_xor(x, 2 * IPF);
-      unsigned nbk = (pl.nb[k >> 2] >> (8 * (k & 3))) & 0xffu;
-      nbk += __shfl_xor(nbk, IPF);
-      nbk += __shfl_xor(nbk, 2 * IPF);
-      if (g == 0) {
-        int col = kk + k * KK + shift;
-        col = col >= M ? col - M : col;
-        q.f0[(size_t)pl.run * M + col] = x & ~pad;
-        q.f1[(size_t)pl.run * M + col] = x | pad;
-        q.below_run[(size_t)pl.run * M + col] = (unsigned char)nbk;
-      }
-    }
-    if (tid == 0) {
-      q.cand_n[pl.run] = pl.cnt;
-      if (pl.cnt > (unsigned)q.cap) atomicOr(q.flags, 1u);
-    }
-  }
-
   // FULL: every frame of the chunk exists (an interior run): the stores are unconditional, so that the number of
   // vector-memory operations per step is the same on every path -- the compiler's s_waitcnt counts stay exact across
   // the chunk loop (a conditional store makes it assume the fewest, i.e. wait for MORE than the load it needs)
   // MAGSEL: -1 = PFB_FLAG_MAGNITUDE is tested here, 0 / 1 = the caller has (outside its chunk loop: same reason as FULL)
-  // TWLDS: the pass's twiddle rows come from the workgroup's LDS copy `twl` (fill_twiddles) -- neither 2 R registers
-  // nor table loads that would queue behind the row prefetch
-  template <int I, bool PDW = false, bool FULL = false, int MAGSEL = -1, bool TWLDS = false>
+  template <int I, bool FULL = false, int MAGSEL = -1>
   PFB_DEV void pass(const KernelParams& p, float2* src, float2* dst, int tid, long long f0,
-                    const v2f (&tw)[2][16], float2* out_base = nullptr, long long frames_lim = -1, PdwLane* pl = nullptr,
-                    const float4* thr = nullptr, long long f_run = 0, const float2* twl = nullptr) {
-    float2* const p_out = out_base ? out_base : p.out;
-    const long long p_frames = frames_lim >= 0 ? frames_lim : p.frames;
+                    const v2f (&tw)[2][16]) {
+    float2* const p_out = p.out;
+    const long long p_frames = p.frames;
     constexpr int R = K::R(I), S = K::S(I), KK = K::K(I), RS = K::RS(I);
     constexpr int IPF = M / R, ITEMS = C * IPF, ITERS = (ITEMS + NT - 1) / NT;
     constexpr bool LAST = (I == K::NP - 1);
@@ -579,15 +502,7 @@ struct FastKernel {
       if constexpr (!LAST) {
         constexpr int S1 = K::S(I + 1), RS1 = K::RS(I + 1);
         // twiddle e^{+j 2 pi rest k / (R S)}: row `rest` of this pass's table
-        if constexpr (TWLDS) {
-          const float4* t4 = reinterpret_cast<const float4*>(twl + TWL_OFF(I) + rest * TWS(I));
-#pragma unroll
-          for (int k2 = 0; k2 < K::TWR(I) / 2; ++k2) {
-            const float4 t = t4[k2];
-            if (k2 > 0) x[2 * k2] = cmul_w(x[2 * k2], (v2f){t.x, t.y});
-            if (2 * k2 + 1 < R) x[2 * k2 + 1] = cmul_w(x[2 * k2 + 1], (v2f){t.z, t.w});
-          }
-        } else if constexpr (TW_REGS) {
+        if constexpr (TW_REGS) {
 #pragma unroll
           for (int k = 1; k < R; ++k) x[k] = cmul_w(x[k], tw[I][k]);
         } else {
@@ -705,7 +620,6 @@ struct FastKernel {
             for (int k = 0; k < R; ++k) {
               const v2f v = derot(x[k], k);
               store_c64(slot(row, k), v, p.nontemporal);
-              if constexpr (PDW) pdw_visit(p, *pl, thr, v, k, col_of(kk + k * KK), (int)((f - f_run) >> 2), f);
             }
           }
         }
@@ -827,9 +741,9 @@ struct FastKernel {
 
   // FIR of C frames from the window x (x[i] = row f0-(W-1)+i) into LDS, then the FFT passes and the
   // stores.  u_{p_lo + D ph}[t] = sum_q h[ph + OS q] * x[row t - ph - OS q]: one v_pk_fma_f32 per tap.
-  template <bool WAVE_LOCAL = false, bool TRANSPOSED = false, bool PDW = false, bool FULL = false, int MAGSEL = -1>
+  template <bool WAVE_LOCAL = false, bool TRANSPOSED = false, bool FULL = false, int MAGSEL = -1>
   PFB_DEV void fir_fft_store(const KernelParams& p, const Consts& k, const v2f (&x)[NW][CPT], float2* lds, int tid,
-                             long long f0, PdwLane* pl = nullptr, const float4* thr = nullptr, long long f_run = 0) {
+                             long long f0) {
     float2* buf0 = lds;
     float2* buf1 = K::PINGPONG ? lds + K::BUF : lds;
 #pragma unroll
@@ -863,11 +777,11 @@ struct FastKernel {
       last_pass_transposed(p, buf1, tid, f0);
       return;
     } else if constexpr (K::NP == 2) {
-      pass<1, PDW, FULL, MAGSEL>(p, buf1, nullptr, tid, f0, k.tw, nullptr, -1, pl, thr, f_run);
+      pass<1, FULL, MAGSEL>(p, buf1, nullptr, tid, f0, k.tw);
     } else {
       pass<1>(p, buf1, buf0, tid, f0, k.tw);
       team_sync<WAVE_LOCAL>();
-      pass<2, false, FULL, MAGSEL>(p, buf0, nullptr, tid, f0, k.tw);
+      pass<2, FULL, MAGSEL>(p, buf0, nullptr, tid, f0, k.tw);
     }
     team_sync<WAVE_LOCAL>();  // the next chunk's FIR overwrites buf0
   }
@@ -910,19 +824,10 @@ struct FastKernel {
   // (MAGSEL / interior runs: the loop issues the same vector-memory operations on every path and is rotated -- the next
   // chunk's rows, requested before this chunk's FIR, are taken at the END of the iteration -- so that the compiler's
   // s_waitcnt for them counts the chunk's stores exactly instead of waiting for them too: see pass<FULL>)
-  template <bool INTERIOR, bool PDW = false, int MAGSEL = -1>
-  PFB_DEV void run_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end,
-                        const float4* thr = nullptr) {
+  template <bool INTERIOR, int MAGSEL = -1>
+  PFB_DEV void run_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end) {
     const int tid = threadIdx.x;
     const int c0 = tid * CPT;
-    PdwLane pl;
-    if constexpr (PDW) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pl.ov[i] = 0u;
-      pl.nb[0] = pl.nb[1] = 0u;
-      pl.cnt = 0u;
-      pl.run = (int)(f_begin / 64);
-    }
     // uniform pointer to (row f_begin-(W-1), column 0); only dereferenced on the INTERIOR path
     const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
     v2f x[NW][CPT];
@@ -946,23 +851,21 @@ struct FastKernel {
     };
     take_rows();
     for (long long f0 = f_begin; f0 < f_end; f0 += C) {
-      if constexpr (INTERIOR && !PDW) {  // the next chunk's rows under this chunk's FFT; past the run's end: its last chunk again
+      if constexpr (INTERIOR) {  // the next chunk's rows under this chunk's FFT; past the run's end: its last chunk again
         const long long nxt = f0 + C < f_end ? f0 + C : f0;
         load_rows<true>(p, run_ptr, nxt, (nxt - f_begin) + (W - 1), c0, raw, rf);
       } else if (f0 + C < f_end) {
         const long long rel = (f0 - f_begin) + C + (W - 1);
         load_rows<INTERIOR>(p, run_ptr, f0 + C, rel, c0, raw, rf);
       }
-      fir_fft_store<false, false, PDW, INTERIOR && !PDW, MAGSEL>(p, k, x, lds, tid, f0, &pl, thr, f_begin);
+      fir_fft_store<false, false, INTERIOR, MAGSEL>(p, k, x, lds, tid, f0);
       // slide the window by C rows
 #pragma unroll
       for (int i = 0; i < W - 1; ++i)
 #pragma unroll
         for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
-      if (INTERIOR && !PDW) take_rows();
-      else if (f0 + C < f_end) take_rows();
+      if (INTERIOR || f0 + C < f_end) take_rows();
     }
-    if constexpr (PDW) pdw_finish_run(p, pl, tid, f_begin, f_end, (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0);
   }
 
   template <int MAGSEL = -1>
@@ -982,8 +885,8 @@ struct FastKernel {
     setup(p, threadIdx.x, k);
     // every row of the run (halo included) lies inside `in`, whole chunks only, aligned vectors
     const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_last <= p.frames);
-    if (interior) run_impl<true, false, MAGSEL>(p, k, lds, f_begin, f_end);
-    else run_impl<false, false, MAGSEL>(p, k, lds, f_begin, f_end);
+    if (interior) run_impl<true, MAGSEL>(p, k, lds, f_begin, f_end);
+    else run_impl<false, MAGSEL>(p, k, lds, f_begin, f_end);
   }
 
   // ---- schedule P: schedule A software-pipelined inside the wave ---------------------------------------------------
@@ -1036,19 +939,9 @@ struct FastKernel {
   // rows requested two chunks ahead stops waiting for half of the previous chunk's stores as well (pass<FULL>)
   // (tried for cfg3, whose 4 columns per lane spill 16-26 registers inside this loop: pass 0's twiddles from an LDS copy
   // instead of 30 registers -- the spills stayed, the rate fell from 0.64 to 0.50; cfg3 went back to schedule 0)
-  static constexpr bool kOverlapTwLds = false;
-  template <bool INTERIOR, bool PDW = false, int MAGSEL = -1>
-  PFB_DEV void run_overlap_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end,
-                                const float4* thr = nullptr, const float2* twl = nullptr) {
+  template <bool INTERIOR, int MAGSEL = -1>
+  PFB_DEV void run_overlap_impl(const KernelParams& p, const Consts& k, float2* lds, long long f_begin, long long f_end) {
     static_assert(NT == 64 && K::NP == 2 && !K::PINGPONG, "single-wave two-pass plans");
-    PdwLane pl;
-    if constexpr (PDW) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pl.ov[i] = 0u;
-      pl.nb[0] = pl.nb[1] = 0u;
-      pl.cnt = 0u;
-      pl.run = (int)(f_begin / 64);
-    }
     const int tid = threadIdx.x;
     const int c0 = tid * CPT;
     const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
@@ -1098,45 +991,22 @@ struct FastKernel {
       load_chunk_rows(ci + 2);     // two chunks ahead
       // one basic block: the next chunk's FIR next to this chunk's first pass
       fir_compute(k, x, acc);
-      pass<0, false, false, -1, kOverlapTwLds>(p, cur, cur, tid, f_begin + ci * C, k.tw, nullptr, -1, nullptr, nullptr, 0, twl);
+      pass<0>(p, cur, cur, tid, f_begin + ci * C, k.tw);
       slide();
       team_sync<true>();
-      pass<1, PDW, INTERIOR, MAGSEL>(p, cur, nullptr, tid, f_begin + ci * C, k.tw, nullptr, -1, &pl, thr, f_begin);
+      pass<1, INTERIOR, MAGSEL>(p, cur, nullptr, tid, f_begin + ci * C, k.tw);
       fir_write(k, acc, nxt, tid);
       team_sync<true>();
       float2* t = cur; cur = nxt; nxt = t;
       take_rows();                 // rows of chunk ci + 2 (waits for them; the chunk's stores stay in flight)
     }
-    pass<0, false, false, -1, kOverlapTwLds>(p, cur, cur, tid, f_begin + (nchunks - 1) * C, k.tw, nullptr, -1, nullptr, nullptr, 0, twl);
+    pass<0>(p, cur, cur, tid, f_begin + (nchunks - 1) * C, k.tw);
     team_sync<true>();
-    pass<1, PDW, INTERIOR, MAGSEL>(p, cur, nullptr, tid, f_begin + (nchunks - 1) * C, k.tw, nullptr, -1, &pl, thr, f_begin);
-    if constexpr (PDW) pdw_finish_run(p, pl, tid, f_begin, f_end, (p.flags & PFB_FLAG_FFTSHIFT) ? (M / 2) : 0);
-  }
-
-  // the same runs with the PDW screen in the last pass; thr: this workgroup's copy of the per-column screens in LDS
-  PFB_DEV void run_overlap_pdw(const KernelParams& p, float2* lds, float4* thr) {
-    static_assert(kPdwOk, "shape of the fused screen");
-    long long run = blockIdx.x;
-    if (p.xcd_remap) {
-      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
-      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
-    }
-    const long long f_begin = run * 64;
-    if (f_begin >= p.frames) return;
-    const long long f_last = f_begin + 64;
-    const long long f_end = f_last < p.frames ? f_last : p.frames;
-    for (int c = threadIdx.x; c < M; c += NT) thr[c] = p.pdw->thr[c];
-    Consts k;
-    setup(p, threadIdx.x, k);
-    team_sync<true>();
-    const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_last <= p.frames);
-    // the plain sliding kernel, not the software-pipelined one: that one has no registers left for the screen (105 spilled)
-    if (interior) run_impl<true, true>(p, k, lds, f_begin, f_end, thr);
-    else run_impl<false, true>(p, k, lds, f_begin, f_end, thr);
+    pass<1, INTERIOR, MAGSEL>(p, cur, nullptr, tid, f_begin + (nchunks - 1) * C, k.tw);
   }
 
   template <int MAGSEL = -1>
-  PFB_DEV void run_overlap(const KernelParams& p, float2* lds, float2* twl = nullptr) {
+  PFB_DEV void run_overlap(const KernelParams& p, float2* lds) {
     long long run = blockIdx.x;
     if (p.xcd_remap) {
       const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
@@ -1149,12 +1019,8 @@ struct FastKernel {
     Consts k;
     setup(p, threadIdx.x, k);
     const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_last <= p.frames);
-    if constexpr (kOverlapTwLds) {
-      fill_twiddles(p, twl);
-      team_sync<true>();
-    }
-    if (interior) run_overlap_impl<true, false, MAGSEL>(p, k, lds, f_begin, f_end, nullptr, twl);
-    else run_overlap_impl<false, false, MAGSEL>(p, k, lds, f_begin, f_end, nullptr, twl);
+    if (interior) run_overlap_impl<true, MAGSEL>(p, k, lds, f_begin, f_end);
+    else run_overlap_impl<false, MAGSEL>(p, k, lds, f_begin, f_end);
   }
 
   // ---- schedule T: FIR team + FFT team (large M) --------------------------------------------------------
@@ -1214,31 +1080,21 @@ struct FastKernel {
   // FIR team: chunk ci into buffer ci % 3, then the LAST pass (and the stores) of chunk ci - 2, whose first two
   // passes the FFT team finished in the step before.  The stores are most of the FFT's memory work and the FIR
   // team has issue slots to spare, while four FFT waves doing everything were the bottleneck (2.4 of 2.9 ms).
-  // TF > 0 (channel-major handles): the last pass writes its frame-major rows into one of this workgroup's two scratch
-  // tiles of TF frames (global memory, rewritten every other tile, so it lives in L2 / the memory-side cache) instead of
-  // `out`; the FFT team moves finished tiles into place transposed, a slice per chunk step (flush_unit below).  The FIR
-  // team's only extra duty: at a tile's last chunk its stores must have LEFT before the step's barrier.
-  template <bool INTERIOR, int TF = 0, int MAGSEL = -1>
-  PFB_DEV void fir_team(const KernelParams& p, const Consts& k, float2* bufs, long long f_begin, int nch,
-                        float2* sc = nullptr, int tile_base = 0) {
+  // (A variant of this kernel for channel-major handles -- the last pass writing frame-major scratch tiles that the FFT
+  // team moved into place transposed -- measured slower than frame-major slabs plus a transpose kernel, 7.4 against 6.4 ms
+  // per 2^30 samples at M = 1024, and was removed: DESIGN.md section 5.4.)
+  template <bool INTERIOR, int MAGSEL = -1>
+  PFB_DEV void fir_team(const KernelParams& p, const Consts& k, float2* bufs, long long f_begin, int nch) {
     const int tid = threadIdx.x;
     const int c0 = tid * CPT;
-    static_assert(TF == 0 || (OS == 1 && TF % C == 0), "critically sampled team plans, whole chunks per tile");
-    constexpr int CPTL = TF > 0 ? TF / C : 1;  // chunks per tile
     auto last_pass = [&](float2* buf, int c) {   // chunk c of this run
-      if constexpr (TF > 0) {
-        float2* tile = sc + (size_t)((tile_base + c / CPTL) & 1) * TF * M;
-        pass<K::NP - 1>(p, buf, nullptr, tid, (long long)(c % CPTL) * C, k.tw, tile, TF);
-        if (c % CPTL == CPTL - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile is complete: visible behind the next barrier
-      } else {
-        // the thread index is laundered so that everything the pass derives from it (LDS and store addresses) is
-        // recomputed here -- a few VALU instructions -- instead of being hoisted out of the chunk loop: hoisted, ONE of
-        // them was spilled, and its reload (a vector-memory load, which returns in order) made every step wait for the
-        // row prefetch issued just before it: s_waitcnt vmcnt(0) four times per iteration of the steady-state loop
-        int t2 = tid;
-        asm volatile("" : "+v"(t2));
-        pass<K::NP - 1, false, INTERIOR, MAGSEL>(p, buf, nullptr, t2, f_begin + (long long)c * C, k.tw);
-      }
+      // the thread index is laundered so that everything the pass derives from it (LDS and store addresses) is
+      // recomputed here -- a few VALU instructions -- instead of being hoisted out of the chunk loop: hoisted, ONE of
+      // them was spilled, and its reload (a vector-memory load, which returns in order) made every step wait for the
+      // row prefetch issued just before it: s_waitcnt vmcnt(0) four times per iteration of the steady-state loop
+      int t2 = tid;
+      asm volatile("" : "+v"(t2));
+      pass<K::NP - 1, INTERIOR, MAGSEL>(p, buf, nullptr, t2, f_begin + (long long)c * C, k.tw);
     };
     const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
     v2f x[NW][CPT];
@@ -1270,23 +1126,12 @@ struct FastKernel {
 #pragma unroll
         for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f0 + 2 * C + t, rel + t, c0, raw[U][t]);
       }
-      // (TF > 0: the stores first, so that at a tile's end they have the FIR's time to leave before the wait for them)
-      if constexpr (TF > 0 && LASTP) {
-        pass<K::NP - 1>(p, bufs + b_last * K::BUF, nullptr, tid, (long long)((ci - 2) % CPTL) * C, k.tw,
-                        sc + (size_t)((tile_base + (ci - 2) / CPTL) & 1) * TF * M, TF);
-      }
       fir_to_lds(k, x, bufs + b_fir * K::BUF, tid);
 #pragma unroll
       for (int i = 0; i < W - 1; ++i)
 #pragma unroll
         for (int cc = 0; cc < CPT; ++cc) x[i][cc] = x[i + C][cc];
-      if constexpr (LASTP) {
-        if constexpr (TF > 0) {
-          if ((ci - 2) % CPTL == CPTL - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile is complete: visible behind the barrier
-        } else {
-          last_pass(bufs + b_last * K::BUF, ci - 2);
-        }
-      }
+      if constexpr (LASTP) last_pass(bufs + b_last * K::BUF, ci - 2);
       __syncthreads();  // (barrier ci) chunk ci handed to the FFT team, buffer of chunk ci - 2 free again
       b_fir = (b_fir == 2) ? 0 : b_fir + 1;
       b_last = (b_last == 2) ? 0 : b_last + 1;
@@ -1302,163 +1147,41 @@ struct FastKernel {
     __syncthreads();  // (barrier nch)
     b_last = (b_last == 2) ? 0 : b_last + 1;
     last_pass(bufs + b_last * K::BUF, nch - 1);
-    if constexpr (TF > 0) __syncthreads();  // (barrier nch + 1) the run's last tile handed to the FFT team
   }
 
-  // One slice of a finished tile, by ONE FFT wave with its own small LDS tile (no workgroup barrier involved): unit u =
-  // 32 channels x TF frames of the frame-major scratch tile -> TF consecutive frames of 32 channel rows of `out`
-  // (256-byte runs at TF = 32, two channels per store instruction).  The scratch reads bypass L1 (nontemporal:
-  // L2-served), so what the last pass wrote a moment ago is what comes back whatever this CU's L1 holds from before.
-  template <int TF>
-  struct TileFlush {
-    static constexpr int TROW = TF + 1, TILE = 32 * TROW;  // per FFT wave; padded rows: conflict-free transposed writes
-    static constexpr int UNITS = (M + 31) / 32;            // per tile
-    static constexpr int STEPS = TF / C;                   // chunk steps until the scratch tile is written again
-    static constexpr int UPS = (UNITS + C * STEPS - 1) / (C * STEPS);  // units per FFT wave and step
-    static_assert(TF % 2 == 0 && (64 * TF) % 64 == 0, "two frames per load instruction");
-  };
-
-  // the two halves of a unit's flush: the loads are issued at the top of a chunk step and land under the step's FFT
-  // passes; transposition and stores follow the passes (a dependent load -> LDS -> store chain inside one step made the
-  // FFT waves the kernel's critical path: 5.9 ms instead of 2.7 per 2^30 samples at M = 1024)
-  template <int TF>
-  PFB_DEV void flush_load(const float2* tile, int u, int lane, v2f (&v)[TF / 2]) {
-    const int ch0 = u * 32;
-    if (ch0 >= M) return;  // wave-uniform
-    const int lc = lane & 31, lf = lane >> 5;
-    const v2f* src = reinterpret_cast<const v2f*>(tile) + (ch0 + lc < M ? ch0 + lc : 0);
-#pragma unroll
-    for (int i = 0; i < TF / 2; ++i) v[i] = __builtin_nontemporal_load(src + (size_t)(2 * i + lf) * M);
-  }
-
-  template <int TF>
-  PFB_DEV void flush_store(const KernelParams& p, float2* lds_tile, int u, long long f_tile0, int lane, const v2f (&v)[TF / 2]) {
-    constexpr int TROW = TileFlush<TF>::TROW;
-    static_assert(M % 2 == 0 && TF == 32, "a store instruction is two channels x 32 frames");
-    const int ch0 = u * 32;
-    if (ch0 >= M) return;  // wave-uniform
-    v2f* T = reinterpret_cast<v2f*>(lds_tile);
-    const int lc = lane & 31, lf = lane >> 5;
-    v2f* wr = T + lc * TROW + lf;  // + 2 i: immediate offsets
-#pragma unroll
-    for (int i = 0; i < TF / 2; ++i) wr[2 * i] = v[i];
-    team_sync<true>();
-    // element i of this lane: channel ch0 + 2 i + lf, frame lc.  One LDS address and one global pointer, both advanced
-    // by constants (the opaque asm keeps the compiler from materialising sixteen 64-bit addresses: they spilled, and every
-    // reload sat behind an s_waitcnt vmcnt(0), i.e. behind the previous STORE's acknowledgement: 12 ms instead of 4)
-    const v2f* rd = T + lf * TROW + lc;  // + i * 2 * TROW
-    const long long fg = f_tile0 + lc;
-    typedef __attribute__((address_space(1))) v2f gv2f;  // stays a GLOBAL pointer behind the asm (a generic one becomes flat_store)
-    gv2f* ptr = (gv2f*)(p.out + (long long)(ch0 + lf) * p.out_ld + p.out_frame0 + fg);
-    const long long step = 2 * p.out_ld;
-    v2f val[TF / 2];
-#pragma unroll
-    for (int i = 0; i < TF / 2; ++i) val[i] = rd[i * 2 * TROW];
-    if (fg < p.frames) {
-#pragma unroll
-      for (int i = 0; i < TF / 2; ++i) {
-        if (M % 32 == 0 || ch0 + 2 * i < M) *ptr = val[i];  // wave-uniform: M is even, so a pair of channels is in or out together
-        asm volatile("" : "+v"(ptr) : : "memory");
-        ptr += step;
-      }
-    }
-    team_sync<true>();  // the next unit overwrites the LDS tile
-  }
-
-  template <int TF = 0, int MAGSEL = -1>
-  PFB_DEV void run_teams(const KernelParams& p, float2* bufs, float2* tiles = nullptr) {
+  template <int MAGSEL = -1>
+  PFB_DEV void run_teams(const KernelParams& p, float2* bufs) {
     static_assert(K::NP == 3 && !K::PINGPONG && NT % 64 == 0, "three in-place passes");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nch = p.frames_per_block / C;  // even (host rounds); the last workgroup filters zero padding past the end
     Consts k;
     setup(p, wave < NT / 64 ? threadIdx.x : lane, k);  // FFT team: only the twiddles are used, rows `lane % S` of the passes' tables
-    // frame-major: one run per workgroup, in dispatch order.  TF > 0: resident workgroups walk runs b, b + G, ... and
-    // own scratch slot b (two tiles; the grid is what fits the chip at once, so the scratch is 2 x TF frames per CU)
-    using TFL = TileFlush<(TF > 0 ? TF : 2 * C)>;
-    constexpr int CPTL = TF > 0 ? TF / C : 1, TPR_DUMMY = 0;
-    (void)TPR_DUMMY;
-    const long long nruns = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
-    float2* sc = TF > 0 ? reinterpret_cast<float2*>(p.scratch) + (size_t)blockIdx.x * 2 * TF * M : nullptr;
-    const int tiles_per_run = TF > 0 ? nch / CPTL : 0;
-    int tile_base = 0;  // tiles this workgroup has produced before the current run (parity picks the scratch tile)
-    // FFT team: the tile being flushed
-    int pend = 0, pend_buf = 0;
-    long long pend_f0 = 0;
-    const int fr = wave - NT / 64;  // FFT team: my frame inside every chunk
-    v2f fv[TFL::UPS][(TF > 0 ? TF : 2 * C) / 2];  // the slice in flight
-    bool loaded = false;            // fv holds the slice the next flush_end stores
-    auto flush_fetch = [&]() {
-      if constexpr (TF > 0) {
-        const int j = TFL::STEPS - pend;
-#pragma unroll
-        for (int q = 0; q < TFL::UPS; ++q)
-          flush_load<TF>(sc + (size_t)pend_buf * TF * M, (j * TFL::UPS + q) * C + fr, lane, fv[q]);
-        loaded = true;
-      }
-    };
-    auto flush_begin = [&]() {      // FFT team, top of a chunk step: a tile's FIRST slice is loaded here ...
-      if constexpr (TF > 0) {
-        if (pend > 0 && !loaded) flush_fetch();
-      }
-    };
-    auto flush_end = [&]() {        // ... after the step's FFT passes the slice goes through LDS and out, and the NEXT slice's
-      if constexpr (TF > 0) {       // loads are issued behind the stores: a whole chunk step for both to complete
-        if (pend > 0) {
-          const int j = TFL::STEPS - pend;
-#pragma unroll
-          for (int q = 0; q < TFL::UPS; ++q)
-            flush_store<TF>(p, tiles + fr * TFL::TILE, (j * TFL::UPS + q) * C + fr, pend_f0, lane, fv[q]);
-          --pend;
-          loaded = false;
-          if (pend > 0) flush_fetch();
-        }
-      }
-    };
-    for (long long blk = blockIdx.x; blk < nruns; blk += (TF > 0 ? (long long)gridDim.x : nruns)) {
-      long long run = blk;
-      if (TF == 0 && p.xcd_remap) {  // consecutive runs on one XCD: a run's halo rows are its predecessor's last rows, still in that L2
-        const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
-        run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
-      }
-      const long long f_begin = run * p.frames_per_block;
-      if (f_begin >= p.frames) break;
-      if (wave < NT / 64) {
-        const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_begin + p.frames_per_block <= p.frames);
-        if (interior) fir_team<true, TF, MAGSEL>(p, k, bufs, f_begin, nch, sc, tile_base);
-        else fir_team<false, TF, MAGSEL>(p, k, bufs, f_begin, nch, sc, tile_base);
-      } else {
-        // (s_setprio for either team, measured: cfg4 -3 % / 0, M=560 +1.6 % / +1 %: noise)
-        int b = 0;          // buffer of chunk s - 1
-#pragma unroll 1
-        for (int s = 0; s <= nch; ++s) {
-          flush_begin();
-          if (s >= 1) {
-            float2* fbuf = bufs + b * K::BUF + fr * K::FS;
-            pass_frame<0>(p, fbuf, lane, k.tw);
-            team_sync<true>();
-            pass_frame<1>(p, fbuf, lane, k.tw);
-            b = (b == 2) ? 0 : b + 1;
-          }
-          flush_end();
-          __syncthreads();  // (barrier s) behind it the FIR team's last pass of chunk s - 2 is done -- and, at a tile's end, visible
-          if constexpr (TF > 0) {
-            if (s >= 2 && (s - 2) % CPTL == CPTL - 1) {
-              const int tc = (s - 2) / CPTL;
-              pend = TFL::STEPS; pend_buf = (tile_base + tc) & 1; pend_f0 = f_begin + (long long)tc * TF; loaded = false;
-            }
-          }
-        }
-        if constexpr (TF > 0) {
-          __syncthreads();  // (barrier nch + 1) the run's last tile
-          while (pend > 0) { flush_begin(); flush_end(); }  // the tile before it was a step short of done (the run ended)
-          pend = TFL::STEPS; pend_buf = (tile_base + tiles_per_run - 1) & 1; pend_f0 = f_begin + (long long)(tiles_per_run - 1) * TF;
-          loaded = false;
-        }
-      }
-      tile_base += tiles_per_run;
+    long long run = blockIdx.x;  // one run per workgroup, in dispatch order
+    if (p.xcd_remap) {  // consecutive runs on one XCD: a run's halo rows are its predecessor's last rows, still in that L2
+      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
+      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
     }
-    if constexpr (TF > 0) {
-      if (wave >= NT / 64) while (pend > 0) { flush_begin(); flush_end(); }  // the last tile of the last run: nobody to keep step with
+    const long long f_begin = run * p.frames_per_block;
+    if (f_begin >= p.frames) return;
+    if (wave < NT / 64) {
+      const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_begin + p.frames_per_block <= p.frames);
+      if (interior) fir_team<true, MAGSEL>(p, k, bufs, f_begin, nch);
+      else fir_team<false, MAGSEL>(p, k, bufs, f_begin, nch);
+    } else {
+      // (s_setprio for either team, measured: cfg4 -3 % / 0, M=560 +1.6 % / +1 %: noise)
+      const int fr = wave - NT / 64;  // my frame inside every chunk
+      int b = 0;                      // buffer of chunk s - 1
+#pragma unroll 1
+      for (int s = 0; s <= nch; ++s) {
+        if (s >= 1) {
+          float2* fbuf = bufs + b * K::BUF + fr * K::FS;
+          pass_frame<0>(p, fbuf, lane, k.tw);
+          team_sync<true>();
+          pass_frame<1>(p, fbuf, lane, k.tw);
+          b = (b == 2) ? 0 : b + 1;
+        }
+        __syncthreads();  // (barrier s) behind it the FIR team's last pass of chunk s - 2 is done
+      }
     }
   }
 
@@ -2126,149 +1849,7 @@ struct FastKernel {
     }
   }
 
-  // ---- schedule G: persistent wave pairs ------------------------------------------------------------
-  // Schedule F's workgroups are short-lived (NPAIR * L frames, a dozen microseconds) and only one fits a CU
-  // (LDS), so every workgroup's start-up -- table loads, W-1 halo rows and the first chunk from HBM, the
-  // FFT waves idling through the first step and the FIR waves through the last -- is exposed.  Here a
-  // workgroup stays and walks tiles b, b + G, b + 2G, ...: two steps before a tile ends its FIR wave sends the
-  // NEXT tile's halo rows from HBM straight into the other of two LDS slot sets (global_load_lds, no
-  // registers), in the last step it prefetches the next tile's first chunk like any other chunk, and the FFT
-  // wave's lag of one chunk simply carries across the tile boundary.  Tiles that touch the stream's ends take the checked
-  // loads, unpipelined.
-  template <int NPAIR, int L>
-  struct PersistentPairs {
-    static constexpr int NCH = L / C, TAIL0 = L - (W - 1), SLOT = (W - 1) * D;
-    static_assert(NCH % 2 == 0, "chunk buffers alternate across tile boundaries");
-    static_assert(NT == 64 && L % C == 0 && L >= W - 1 && NCH >= 2, "one wave per run and role");
-
-    PFB_DEV bool interior(const KernelParams& p, long long tile) {
-      const long long f_blk = tile * (long long)(NPAIR * L);
-      return p.vec_ok && ((f_blk - (W - 1)) * D + p.base >= 0) && (f_blk + NPAIR * L <= p.frames);
-    }
-
-    // one tile of the FIR role.  pre: the previous tile already brought this tile's halo rows into its LDS
-    // slot (global_load_lds: HBM -> LDS without passing through registers) and its first chunk into raw[];
-    // next_pre: do the same for the next tile before leaving.
-    template <bool INTERIOR>
-    PFB_DEV void fir_tile(const KernelParams& p, const Consts& k, float2* bufs, raw_t* slots, int set, int pair, int tid,
-                          long long f_begin, long long f_next, bool pre, bool next_pre, raw_t (&raw)[C][CPT]) {
-      static_assert(CPT == 1 && sizeof(raw_t) == 4, "one dword per lane and row");
-      const int c0 = tid;
-      const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
-      raw_t* halo_mine = slots + (set * (NPAIR + 1) + pair) * SLOT;
-      const raw_t* halo_next = slots + (set * (NPAIR + 1) + pair + 1) * SLOT;
-      v2f x[NW][CPT];
-      if (!pre) {
-        raw_t h[W - 1][CPT];
-#pragma unroll
-        for (int i = 0; i < W - 1; ++i) load_row<INTERIOR>(p, run_ptr, f_begin - (W - 1) + i, i, c0, h[i]);
-#pragma unroll
-        for (int t = 0; t < C; ++t) load_row<INTERIOR>(p, run_ptr, f_begin + t, W - 1 + t, c0, raw[t]);
-#pragma unroll
-        for (int i = 0; i < W - 1; ++i) {
-          x[i][0] = cvt(h[i][0]);
-          if constexpr (INTERIOR) halo_mine[i * D + c0] = h[i][0];
-        }
-        __syncthreads();  // A: halo slots published
-      } else {
-#pragma unroll
-        for (int i = 0; i < W - 1; ++i) x[i][0] = cvt(halo_mine[i * D + c0]);
-      }
-      const bool tail_from_lds = INTERIOR && (pair < NPAIR - 1);
-      const raw_t* next_ptr = static_cast<const raw_t*>(p.in) + ((f_next - (W - 1)) * D + p.base);
-#pragma unroll
-      for (int ci = 0; ci < NCH; ++ci) {
-#pragma unroll
-        for (int t = 0; t < C; ++t) {
-          const int r = ci * C + t;
-          if (r >= TAIL0 && tail_from_lds) x[W - 1 + t][0] = cvt(halo_next[(r - TAIL0) * D + c0]);
-          else x[W - 1 + t][0] = cvt(raw[t][0]);
-        }
-        if (ci + 1 < NCH) {
-#pragma unroll
-          for (int t = 0; t < C; ++t) {
-            const int r = (ci + 1) * C + t;
-            if (!(r >= TAIL0 && tail_from_lds)) load_row<INTERIOR>(p, run_ptr, f_begin + r, W - 1 + r, c0, raw[t]);
-          }
-        } else if constexpr (INTERIOR) {
-          if (next_pre) {  // the next tile's first chunk, a step ahead like any other chunk
-#pragma unroll
-            for (int t = 0; t < C; ++t) load_row<true>(p, next_ptr, 0, W - 1 + t, c0, raw[t]);
-          }
-        }
-        if constexpr (INTERIOR) {
-          if (ci == NCH - 2 && next_pre) {  // the next tile's halo rows: HBM -> the other slot set, two steps ahead
-            raw_t* dst = slots + ((set ^ 1) * (NPAIR + 1) + pair) * SLOT;
-#pragma unroll
-            for (int i = 0; i < W - 1; ++i)
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(next_ptr + i * D + c0),
-                                               (__attribute__((address_space(3))) void*)(dst + i * D), 4, 0, 0);
-          }
-        }
-        fir_to_lds(k, x, bufs + (ci & 1) * K::BUF, tid);
-#pragma unroll
-        for (int i = 0; i < W - 1; ++i) x[i][0] = x[i + C][0];
-        __syncthreads();  // chunk ci handed to the FFT wave (and, at the end, the next tile's halo is in place)
-      }
-    }
-
-    PFB_DEV void run(const KernelParams& p, float2* lds_fft, raw_t* slots) {
-      const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
-      const bool fir_role = wave < NPAIR;
-      const int pair = fir_role ? wave : wave - NPAIR;
-      const long long per_tile = (long long)NPAIR * L;
-      const long long ntiles = (p.frames + per_tile - 1) / per_tile, G = gridDim.x;
-      float2* bufs = lds_fft + pair * 2 * K::BUF;
-      Consts k;
-      setup(p, tid, k);
-      if (fir_role) {
-        raw_t raw[C][CPT];
-        bool pre = false;
-        int set = 0;
-        for (long long tile = blockIdx.x; tile < ntiles; tile += G, set ^= 1) {
-          const bool in = interior(p, tile);
-          const bool next_pre = in && (tile + G < ntiles) && interior(p, tile + G);
-          const long long f_begin = tile * per_tile + (long long)pair * L;
-          const long long f_next = (tile + G) * per_tile + (long long)pair * L;
-          if (in) fir_tile<true>(p, k, bufs, slots, set, pair, tid, f_begin, f_next, pre, next_pre, raw);
-          else fir_tile<false>(p, k, bufs, slots, set, pair, tid, f_begin, f_next, false, false, raw);
-          pre = next_pre;
-        }
-      } else {
-        bool pending = false, pre = false;
-        long long pend_f0 = 0;
-        int pend_buf = 0;
-        for (long long tile = blockIdx.x; tile < ntiles; tile += G) {
-          const bool in = interior(p, tile);
-          const bool next_pre = in && (tile + G < ntiles) && interior(p, tile + G);
-          const long long f_begin = tile * per_tile + (long long)pair * L;
-          if (!pre) {  // the FIR waves load this tile's first rows synchronously: transform under that
-            if (pending) { fft_from_lds(p, k, bufs + pend_buf * K::BUF, tid, pend_f0); pending = false; }
-            __syncthreads();  // A
-          }
-#pragma unroll
-          for (int ci = 0; ci < NCH; ++ci) {
-            if (pending) fft_from_lds(p, k, bufs + pend_buf * K::BUF, tid, pend_f0);
-            __syncthreads();
-            pending = true;
-            pend_f0 = f_begin + (long long)ci * C;
-            pend_buf = ci & 1;
-          }
-          pre = next_pre;
-        }
-        if (pending) fft_from_lds(p, k, bufs + pend_buf * K::BUF, tid, pend_f0);
-      }
-    }
-  };
-
-  // ---- schedule B: persistent waves, strided chunks ---------------------------------------------
-  // The grid is sized to what is resident at once; workgroup b handles chunks b', b'+G, b'+2G, ...
-  // (b' = XCD-aware slot), so at any moment the whole chip works on ~G consecutive chunks: a compact
-  // window sweeping through the stream (DRAM pages and TLB entries are reused while hot; measured
-  // with tools/membench2: the same byte mix moves 15 % faster than with long per-wave runs).  Each
-  // chunk re-reads its W-1 halo rows; its neighbours (same XCD, same step) read those rows as their
-  // own at the same time, so they come from L2, not HBM.  All NW rows of the next chunk are
-  // prefetched into registers under the current chunk's arithmetic.
+  // all NW rows (halo included) of one chunk: schedule C's unit of work
   PFB_DEV void load_chunk(const KernelParams& p, long long chunk, int c0, raw_t (&raw)[NW][CPT]) {
     const long long f0 = chunk * C;
     const long long s_first = (f0 - (W - 1)) * D + p.base;
@@ -2404,31 +1985,6 @@ struct FastKernel {
     }
   }
 
-  PFB_DEV void run_strided(const KernelParams& p, float2* lds) {
-    const int tid = threadIdx.x;
-    const int c0 = tid * CPT;
-    const long long nchunks = (p.frames + C - 1) / C;
-    const long long nb = gridDim.x;
-    long long chunk = blockIdx.x;
-    if (p.xcd_remap) {  // slot = xcd * (nb/8) + index inside the XCD (bijective for any nb)
-      const long long q = nb >> 3, r = nb & 7, xc = chunk & 7;
-      chunk = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (chunk >> 3);
-    }
-    if (chunk >= nchunks) return;
-    Consts k;
-    setup(p, tid, k);
-    raw_t raw[NW][CPT];
-    load_chunk(p, chunk, c0, raw);
-    for (; chunk < nchunks; chunk += nb) {
-      v2f x[NW][CPT];
-#pragma unroll
-      for (int i = 0; i < NW; ++i)
-#pragma unroll
-        for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(raw[i][cc]);
-      if (chunk + nb < nchunks) load_chunk(p, chunk + nb, c0, raw);
-      fir_fft_store(p, k, x, lds, tid, chunk * C);
-    }
-  }
 };
 
 // ---------------------------------------------------------------------------------
@@ -2679,26 +2235,12 @@ __global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_fast_kernel(const Ker
 
 template <class K, bool MAG>
 __global__ void __launch_bounds__(K::NT, (K::MIN_WAVES > 2 ? K::MIN_WAVES - 1 : K::MIN_WAVES)) pfb_overlap_kernel(const KernelParams p) {
-  __shared__ float2 lds[2 * K::BUF + (FastKernel<K>::kOverlapTwLds ? FastKernel<K>::TWL_ELEMS : 0)];
-  FastKernel<K>::template run_overlap<MAG ? 1 : 0>(p, lds, lds + 2 * K::BUF);
+  __shared__ float2 lds[2 * K::BUF];
+  FastKernel<K>::template run_overlap<MAG ? 1 : 0>(p, lds);
 }
 
 template <class K>
 constexpr bool kOverlapOk = K::NT == 64 && K::NP == 2 && !K::PINGPONG;
-
-// schedule 12: schedule 11's runs of 64 frames with the PDW screen fused into the last pass (KernelParams::pdw)
-template <class K>
-__global__ void __launch_bounds__(K::NT, (K::MIN_WAVES > 2 ? K::MIN_WAVES - 1 : K::MIN_WAVES)) pfb_overlap_pdw_kernel(const KernelParams p) {
-  __shared__ float2 lds[2 * K::BUF];
-  __shared__ float4 thr[K::M];
-  FastKernel<K>::run_overlap_pdw(p, lds, thr);
-}
-
-template <class K>
-__global__ void __launch_bounds__(K::NT, (K::MIN_WAVES > 3 ? 3 : K::MIN_WAVES)) pfb_strided_kernel(const KernelParams p) {
-  __shared__ float2 lds[K::LDS_ELEMS];
-  FastKernel<K>::run_strided(p, lds);
-}
 
 template <class K, int NWV, bool CM = false>
 __global__ void __launch_bounds__(64 * NWV) pfb_tile_kernel(const KernelParams p) {
@@ -2764,36 +2306,6 @@ hipError_t launch_paired(const KernelParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <class K, int NPAIR, int L, int MINW>
-__global__ void __launch_bounds__(128 * NPAIR, MINW) pfb_persistent_pairs_kernel(const KernelParams p) {
-  using raw_t = typename SampleT<K::FMT>::raw_t;
-  __shared__ float2 lds_fft[NPAIR * 2 * K::BUF];
-  __shared__ raw_t lds_halo[2 * (NPAIR + 1) * (K::W - 1) * K::D];
-  typename FastKernel<K>::template PersistentPairs<NPAIR, L> pp;
-  pp.run(p, lds_fft, lds_halo);
-}
-
-template <class K, int NPAIR, int L, int MINW>
-hipError_t launch_persistent_pairs(const KernelParams& p, hipStream_t s) {
-  static int resident = 0;  // workgroups resident at once on this device class
-  if (resident == 0) {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pfb_persistent_pairs_kernel<K, NPAIR, L, MINW>,
-                                                                128 * NPAIR, 0);
-    if (e == hipSuccess) e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) return e;
-    resident = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
-  }
-  const long long per = (long long)NPAIR * L;
-  const long long tiles = (p.frames + per - 1) / per;
-  long long grid = p.grid_override > 0 ? p.grid_override : resident;
-  if (grid > tiles) grid = tiles;
-  hipLaunchKernelGGL((pfb_persistent_pairs_kernel<K, NPAIR, L, MINW>), dim3((unsigned)grid), dim3(128 * NPAIR), 0, s, p);
-  return hipGetLastError();
-}
-
 template <class K, int NPAIR, int MINW>
 __global__ void __launch_bounds__(128 * NPAIR, MINW) pfb_pairs_sliding_kernel(const KernelParams p) {
   __shared__ float2 lds_fft[NPAIR * 2 * K::BUF];
@@ -2829,41 +2341,7 @@ __global__ void __launch_bounds__(K::NT, K::MIN_WAVES) pfb_twin_kernel(const Ker
 template <class K, bool MAG>
 __global__ void __launch_bounds__(K::NT + 64 * K::C, K::MIN_WAVES) pfb_teams_kernel(const KernelParams p) {
   __shared__ float2 bufs[3 * K::BUF];
-  FastKernel<K>::template run_teams<0, MAG ? 1 : 0>(p, bufs);
-}
-
-// channel-major for the team plans: the same kernel with its output tile transposed through an L2-resident scratch
-// (FastKernel::flush_tile); frames_per_block must be a multiple of TF
-template <class K, int TF>
-constexpr bool kTeamsCmOk = kTeamsOk<K> && K::D == K::M && TF % K::C == 0 &&
-                            sizeof(float2) * (3 * K::BUF + K::C * FastKernel<K>::template TileFlush<TF>::TILE) <= 160 * 1024;
-
-template <class K, int TF>
-__global__ void __launch_bounds__(K::NT + 64 * K::C, K::MIN_WAVES) pfb_teams_cm_kernel(const KernelParams p) {
-  using TFL = typename FastKernel<K>::template TileFlush<TF>;
-  __shared__ float2 bufs[3 * K::BUF + K::C * TFL::TILE];
-  FastKernel<K>::template run_teams<TF>(p, bufs, bufs + 3 * K::BUF);
-}
-
-template <class K, int TF>
-hipError_t launch_teams_cm(const KernelParams& p, hipStream_t s) {
-  static int resident = 0;  // workgroups resident at once on this device class
-  if (resident == 0) {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pfb_teams_cm_kernel<K, TF>, K::NT + 64 * K::C, 0);
-    if (e == hipSuccess) e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) return e;
-    resident = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
-  }
-  const long long nruns = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
-  long long grid = p.grid_override > 0 ? p.grid_override : resident;
-  if (grid > nruns) grid = nruns;
-  if (grid > p.scratch_slots) grid = p.scratch_slots;  // one scratch tile per workgroup
-  if (grid < 1 || !p.scratch || p.frames_per_block % TF != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((pfb_teams_cm_kernel<K, TF>), dim3((unsigned)grid), dim3(K::NT + 64 * K::C), 0, s, p);
-  return hipGetLastError();
+  FastKernel<K>::template run_teams<MAG ? 1 : 0>(p, bufs);
 }
 
 template <class K, int NWV, int L>
@@ -2897,37 +2375,8 @@ hipError_t launch_shared_impl(const KernelParams& p, hipStream_t s) {
 }
 
 template <class K>
-hipError_t launch_strided(const KernelParams& p, hipStream_t s) {  // persistent strided chunks
-  static int resident = 0;  // workgroups resident at once on this device class
-  if (resident == 0) {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pfb_strided_kernel<K>, K::NT, 0);
-    if (e == hipSuccess) e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) return e;
-    resident = per_cu * prop.multiProcessorCount;
-    if (resident < 8) resident = 8;
-  }
-  const long long nchunks = (p.frames + K::C - 1) / K::C;
-  long long grid = p.grid_override > 0 ? p.grid_override : resident;
-  if (grid > nchunks) grid = nchunks;
-  if (grid >= 8) grid -= grid % 8;
-  hipLaunchKernelGGL(pfb_strided_kernel<K>, dim3((unsigned)grid), dim3(K::NT), 0, s, p);
-  return hipGetLastError();
-}
-
-template <class K>
-constexpr int kTeamsCmFrames = kTeamsCmOk<K, 32> ? 32 : 0;
-
-template <class K>
 hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
   if (p.frames <= 0) return hipSuccess;
-  if constexpr (kTeamsCmFrames<K> > 0) {
-    if (p.layout == PFB_LAYOUT_CHANNEL_MAJOR && p.schedule == 10 && !(p.flags & PFB_FLAG_MAGNITUDE)) {
-      return launch_teams_cm<K, kTeamsCmFrames<K>>(p, s);
-    }
-  }
   if (p.layout == PFB_LAYOUT_CHANNEL_MAJOR) {  // schedules 8, 2 and 0; the others are frame-major tuning
     if constexpr (kChannelMajorOk<K>) {
       if constexpr (K::NT == 64) {
@@ -2980,14 +2429,6 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       return launch_pairs_sliding<K, 6, 3>(p, s);
     }
   }
-  if constexpr (kOverlapOk<K> && FastKernel<K>::kPdwOk) {  // schedule 11 with the PDW screen in the last pass
-    if (p.schedule == 12) {
-      if (!p.pdw || p.layout != PFB_LAYOUT_FRAME_MAJOR || (p.flags & PFB_FLAG_MAGNITUDE)) return hipErrorInvalidValue;
-      const long long nb = (p.frames + 63) / 64;
-      hipLaunchKernelGGL(pfb_overlap_pdw_kernel<K>, dim3((unsigned)nb), dim3(K::NT), 0, s, p);
-      return hipGetLastError();
-    }
-  }
   if constexpr (kOverlapOk<K>) {  // sliding runs, FIR of the next chunk scheduled into the FFT of this one
     if (p.schedule == 11) {
       const long long nb = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
@@ -3015,16 +2456,7 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
     }
   }
   if constexpr (K::NT == 64 && K::NP == 2 && !K::PINGPONG && K::M == 64 && K::C == 8) {
-    constexpr bool kPersistentOk = K::CPT == 1 && sizeof(typename SampleT<K::FMT>::raw_t) == 4;  // dword rows (int16 I/Q)
-    if constexpr (kPersistentOk) {
-      if (p.schedule == 5) {  // persistent wave pairs
-        constexpr size_t kPairP = sizeof(float2) * 2 * K::BUF, kSlotP = sizeof(typename SampleT<K::FMT>::raw_t) * (K::W - 1) * K::D;
-        static_assert(8 * kPairP + 18 * kSlotP <= 160 * 1024, "8 pairs + two halo slot sets fit the LDS");
-        if (p.tile_waves == 4) return launch_persistent_pairs<K, 4, 64, 2>(p, s);
-        return launch_persistent_pairs<K, 8, 64, 4>(p, s);
-      }
-    }
-    if (p.schedule == 4 || p.schedule == 5) {  // FIR / FFT wave pairs: tile_waves = pairs per workgroup, frames_per_block = run length
+    if (p.schedule == 4) {  // FIR / FFT wave pairs: tile_waves = pairs per workgroup, frames_per_block = run length
       const int key = p.tile_waves * 1000 + p.frames_per_block;
       if constexpr (K::FMT == PFB_FMT_INT16_IQ && K::M == 64 && K::P == 12) {  // tuning sweep set (cfg2 only, keeps build time sane)
         switch (key) {
@@ -3074,7 +2506,6 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       if (p.tile_waves == 1) return launch_tile<K, 1>(p, s);
       return launch_tile<K, 8>(p, s);
     }
-    if (p.schedule == 1) return launch_strided<K>(p, s);
   }
   const long long blocks = (p.frames + p.frames_per_block - 1) / p.frames_per_block;
   if constexpr (kMagStagedOk<K>) {

@@ -224,31 +224,30 @@ hipError_t launch_update_history(const void* old_hist, const void* in, long long
 // -> out[col * out_ld + out_frame0 + f].  64 x 64 tiles through LDS: rows are read 64 columns at
 // a time (512 contiguous bytes per wave instruction) and columns written 64 frames at a time (512 contiguous bytes).
 
-// FT frames x 64 channels per tile: a column leaves as FT consecutive frames (FT * sizeof(T) bytes per channel visit).
-// Longer tiles do not help (measured at M = 1024, profiles/r02_channel_major_team_routes.txt: FT = 64 / 128 / 256 move
-// the 2^30-sample matrix in 6.5 / 6.4 / 7.1 ms including the channelizer kernel), so FT = 64 is what runs; with its loads
-// or its stores switched off the kernel costs 0.94 ms less each, with both off the route still takes 3.7 ms against 2.66
-// for the channelizer kernel in one launch: slab by slab, every launch is a single wave of workgroups whose ramp-up and
-// drain nothing hides.  The tile goes through LDS in row groups of 16 frames per wave (16 loads in flight per lane).
-template <typename T, int FT>
+// 64 frames x 64 channels per tile: a column leaves as 64 consecutive frames.  Longer tiles do not help (measured at
+// M = 1024, profiles/r02_channel_major_team_routes.txt: 64 / 128 / 256 frames move the 2^30-sample matrix in 6.5 / 6.4 /
+// 7.1 ms including the channelizer kernel); with its loads or its stores switched off the kernel costs 0.94 ms less each,
+// with both off the route still takes 3.7 ms against 2.66 for the channelizer kernel in one launch: slab by slab, every
+// launch is a single wave of workgroups whose ramp-up and drain nothing hides.  The tile goes through LDS in row groups
+// of 16 frames per wave (16 loads in flight per lane).
+template <typename T>
 __global__ void __launch_bounds__(256) pfb_transpose_slab_kernel(const T* slab, long long frames, int M, T* out,
-                                                                 long long out_ld, long long out_frame0, int probe) {
-  extern __shared__ unsigned char tile_raw[];
-  T (*tile)[FT + 1] = reinterpret_cast<T (*)[FT + 1]>(tile_raw);
+                                                                 long long out_ld, long long out_frame0) {
+  constexpr int FT = 64;
+  __shared__ T tile[64][FT + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = blockIdx.x * 64;
   const long long f0 = (long long)blockIdx.y * FT;
   constexpr int PER_WAVE = FT / 4;  // frames each wave brings in
-#pragma unroll 1
-  for (int g = 0; g < PER_WAVE; g += 16) {
-    T v[16];
+  {
+    T v[PER_WAVE];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const long long f = f0 + wave * PER_WAVE + g + i;
-      v[i] = (f < frames && c0 + lane < M && !(probe & 1)) ? slab[f * M + c0 + lane] : T{};
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const long long f = f0 + wave * PER_WAVE + i;
+      v[i] = (f < frames && c0 + lane < M) ? slab[f * M + c0 + lane] : T{};
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tile[lane][wave * PER_WAVE + g + i] = v[i];
+    for (int i = 0; i < PER_WAVE; ++i) tile[lane][wave * PER_WAVE + i] = v[i];
   }
   __syncthreads();
   // wave w writes channels c0 + 16 w ... + 15: a store instruction is 64 consecutive frames of one channel
@@ -256,47 +255,20 @@ __global__ void __launch_bounds__(256) pfb_transpose_slab_kernel(const T* slab, 
   for (int c = 0; c < 16; ++c) {
     const int col = c0 + wave * 16 + c;
     if (col >= M) break;
-#pragma unroll
-    for (int j = 0; j < FT / 64; ++j) {
-      const long long f = f0 + j * 64 + lane;
-      if (f < frames && !(probe & 2)) out[(long long)col * out_ld + out_frame0 + f] = tile[wave * 16 + c][j * 64 + lane];
-      if ((probe & 2) && lane == 99) out[0] = tile[wave * 16 + c][j * 64 + lane];  // (timing probe: keep the reads alive)
-    }
+    const long long f = f0 + lane;
+    if (f < frames) out[(long long)col * out_ld + out_frame0 + f] = tile[wave * 16 + c][lane];
   }
 }
-
-template <typename T, int FT>
-static hipError_t launch_transpose_slab_t(const void* slab, long long frames, int M, void* out, long long out_ld,
-                                          long long out_frame0, hipStream_t s) {
-  static bool attr_set = false;
-  const size_t lds = sizeof(T) * 64 * (FT + 1);
-  if (!attr_set && lds > 64 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pfb_transpose_slab_kernel<T, FT>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((frames + FT - 1) / FT)), block(256);
-  hipLaunchKernelGGL((pfb_transpose_slab_kernel<T, FT>), grid, block, lds, s, (const T*)slab, frames, M, (T*)out, out_ld, out_frame0,
-                     g_transpose_probe);
-  return hipGetLastError();
-}
-
-int g_transpose_probe = 0;         // timing probe: 1 = no loads, 2 = no stores (PFB_OPT_EXPERIMENT bits 16, 17)
-int g_transpose_tile_frames = 64;  // tuning knob (PFB_OPT_EXPERIMENT bits 8..: 64 / 128 / 256)
 
 hipError_t launch_transpose_slab(const void* slab, long long frames, int M, void* out, long long out_ld,
                                  long long out_frame0, int elem_bytes, hipStream_t s) {
   if (frames <= 0) return hipSuccess;
-  const int ft = g_transpose_tile_frames;
-  if (elem_bytes == 8) {
-    if (ft == 256) return launch_transpose_slab_t<float2, 256>(slab, frames, M, out, out_ld, out_frame0, s);
-    if (ft == 128) return launch_transpose_slab_t<float2, 128>(slab, frames, M, out, out_ld, out_frame0, s);
-    return launch_transpose_slab_t<float2, 64>(slab, frames, M, out, out_ld, out_frame0, s);
-  }
-  if (ft == 256) return launch_transpose_slab_t<float, 256>(slab, frames, M, out, out_ld, out_frame0, s);
-  if (ft == 128) return launch_transpose_slab_t<float, 128>(slab, frames, M, out, out_ld, out_frame0, s);
-  return launch_transpose_slab_t<float, 64>(slab, frames, M, out, out_ld, out_frame0, s);
+  const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((frames + 63) / 64)), block(256);
+  if (elem_bytes == 8)
+    hipLaunchKernelGGL(pfb_transpose_slab_kernel<float2>, grid, block, 0, s, (const float2*)slab, frames, M, (float2*)out, out_ld, out_frame0);
+  else
+    hipLaunchKernelGGL(pfb_transpose_slab_kernel<float>, grid, block, 0, s, (const float*)slab, frames, M, (float*)out, out_ld, out_frame0);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------

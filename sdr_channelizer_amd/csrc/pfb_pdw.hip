@@ -541,7 +541,9 @@ __global__ void __launch_bounds__(256) pdw_bracket_kernel(const float2* y, long 
                                                           int row_groups) {
   constexpr int RPW = 64 / LPR;                                            // rows per wave-load
   constexpr int kBatch = kBracketInFlight < LPR ? kBracketInFlight : LPR;  // a lane owns LPR rows of a word
-  __shared__ float2 stage[4][kBracketSlots][64];
+  // (rows of 65: the flush reads one column c with lanes = (wave, slot) -- 64 rows -- and with rows of 64 float2 every
+  // one of those reads hit the same bank pair, a 32-way conflict: 38 % of the LDS's active cycles in round 2's counters)
+  __shared__ float2 stage[4][kBracketSlots][65];
   __shared__ unsigned char cnt[4][64];
   __shared__ unsigned cand_cnt[64], cand_base[64];
   __shared__ unsigned long long below_acc[64];  // per channel of this workgroup: "below" counts, sent out once at the end

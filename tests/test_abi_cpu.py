@@ -13,9 +13,9 @@ from sdr_channelizer_amd import _lib as L
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
+def declared_symbols(headers=("pfb_channelizer.h", "pfb_iq_packet.h")):
     names = set()
-    for hdr in ("pfb_channelizer.h", "pfb_iq_packet.h"):
+    for hdr in headers:
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(pfb_[a-z0-9_]+)\s*\(", text))
@@ -26,8 +26,14 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     declared = declared_symbols()
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
-    for name in declared:
+    # measurement yardsticks and the ABI self test: their own header, outside the drop-in boundary
+    dev = declared_symbols(("pfb_channelizer_dev.h",))
+    assert dev == set(L.DEV_EXPORTS) and not (dev & declared), dev ^ set(L.DEV_EXPORTS)
+    for name in declared | dev:
         assert hasattr(lib, name), name
+    pub = open(os.path.join(ROOT, "include", "pfb_channelizer.h")).read()
+    for word in ("PFB_OPT_EXPERIMENT", "PFB_OPT_VARIANT", "PFB_OPT_GRID", "PFB_OPT_TILE_WAVES", "pfb_measure_", "pfb_probe_", "pfb_selftest_"):
+        assert word not in pub.replace("PFB_OPT_GRID / TILE_WAVES / EXPERIMENT / VARIANT", ""), word
     assert lib.pfb_abi_version() == L.PFB_ABI_VERSION == 2
 
 
@@ -157,8 +163,9 @@ def test_fft_plan_model_covers_the_registered_plans():
         modelled.add((M, tuple(R), tuple(RS), FS))
     # every FastCfg<...> in the kernel table has its (M, radices, row strides, frame stride) in the model
     csrc = os.path.join(root, "sdr_channelizer_amd", "csrc")
-    src = "".join(open(os.path.join(csrc, f)).read() for f in ("pfb_kernels.hip", "pfb_kernels_mid.hip", "pfb_kernels_big.hip"))
-    assert src.count("FastCfg<") >= 20
+    src = "".join(open(os.path.join(csrc, f)).read() for f in ("pfb_kernels.hip", "pfb_kernels_mid.hip", "pfb_kernels_big.hip",
+                                                                       "pfb_kernels_mixed.hip"))
+    assert src.count("FastCfg<") >= 40
     for args in re.findall(r"FastCfg<([^>]*)>", src):
         a = [t.strip() for t in args.split(",")]
         M, NP = int(a[0]), int(a[6])
@@ -168,7 +175,7 @@ def test_fft_plan_model_covers_the_registered_plans():
 
 
 def test_headers_compile_as_plain_c(tmp_path):
-    """The boundary is a C ABI: both headers must be valid C99 (the recorders are C++, MATLAB's loadlibrary parses C) and
+    """The boundary is a C ABI: the headers (pfb_channelizer.h pulls in pfb_iq_packet.h; the dev header too) must be valid C99 (the recorders are C++, MATLAB's loadlibrary parses C) and
     a C program must link against the library without a C++ runtime of its own."""
     import shutil
     import subprocess
@@ -176,7 +183,7 @@ def test_headers_compile_as_plain_c(tmp_path):
     if gcc is None:
         pytest.skip("no gcc")
     src = tmp_path / "abi_c.c"
-    src.write_text('#include "pfb_channelizer.h"\n#include <stdio.h>\n'
+    src.write_text('#include "pfb_channelizer.h"\n#include "pfb_channelizer_dev.h"\n#include <stdio.h>\n'
                    'int main(void) {\n'
                    '  pfb_config cfg; pfb_shard_config sc; pfb_pdw w; pfb_iq_info info; double f[8];\n'
                    '  (void)cfg; (void)sc; (void)w; (void)info;\n'

@@ -190,15 +190,14 @@ def test_channel_major_device_path_is_bit_identical_to_frame_major():
     (128, 12, 64, "int16", 12, ((2, 0), (8, 8), (8, 16), (9, 64))),
     (256, 8, 256, "int8", 8, ((0, 0), (8, 8), (9, 64))),
     (32, 12, 32, "int16", 12, ((8, 32), (9, 64))),
-    (1024, 16, 1024, "int16", 12, ((-1, 0), (10, 32), (9, 64), (9, 192))),
-    (560, 12, 560, "int16", 12, ((-1, 0), (10, 32), (9, 128))),
+    (1024, 16, 1024, "int16", 12, ((-1, 0), (9, 64), (9, 192))),
+    (560, 12, 560, "int16", 12, ((-1, 0), (9, 128))),
     (20, 12, 20, "int16", 12, ((0, 0), (9, 64)))])
 def test_channel_major_routes_are_bit_identical(M, P, D, fmt, bw, routes):
     """Channel-major output by every route -- the kernel's own stores (schedules 0 and 2), short runs transposed in LDS
-    (schedule 8; frames_per_block = frames per wave), frame-major slabs + the transpose kernel (schedule 9), the team
-    kernel with its tiles transposed through an L2-resident scratch (schedule 10, tiles of 32 or 16 frames; the default
-    of the team plans for complex output) -- with and without fused abs(), over a stream cut into calls: the transposed
-    frame-major result, bit for bit."""
+    (schedule 8; frames_per_block = frames per wave), frame-major slabs + the transpose kernel (schedule 9; the default
+    of the team plans) -- with and without fused abs(), over a stream cut into calls: the transposed frame-major result,
+    bit for bit."""
     import torch
     n = D * 1500 + 11
     iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device="cuda")
@@ -217,10 +216,6 @@ def test_channel_major_routes_are_bit_identical(M, P, D, fmt, bw, routes):
                     b.set_option(L.PFB_OPT_TILE_WAVES, {8: 4, 16: 4, 32: 2}[arg])
                 if sched == 9:
                     b.set_option(L.PFB_OPT_SLAB_FRAMES, arg)
-                if sched == 10:
-                    b.set_option(L.PFB_OPT_TILE_WAVES, 16 if arg == 16 else 8)
-                    if mag:
-                        continue  # fused abs() keeps the slab route
                 got = b(iq)
                 assert torch.equal(got, want), (M, mag, sched, arg)
                 b.reset()
@@ -516,8 +511,6 @@ def test_cfg1_as_the_example_script_calls_it(oracle):
 
 
 @pytest.mark.parametrize("opts", [{L.PFB_OPT_SCHEDULE: 0}, {L.PFB_OPT_SCHEDULE: 0, L.PFB_OPT_FRAMES_PER_BLOCK: 40},
-                                  {L.PFB_OPT_SCHEDULE: 1}, {L.PFB_OPT_SCHEDULE: 1, L.PFB_OPT_GRID: 24},
-                                  {L.PFB_OPT_SCHEDULE: 1, L.PFB_OPT_XCD_REMAP: 0},
                                   {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 1},
                                   {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_XCD_REMAP: 0},
                                   {L.PFB_OPT_SCHEDULE: 2, L.PFB_OPT_TILE_WAVES: 8, L.PFB_OPT_NONTEMPORAL: 1},
@@ -615,35 +608,6 @@ def test_paired_schedule_gives_identical_bits(oracle, tw, fpb):
         ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, fpb)
         got = np.concatenate([ch(iq[:M * 2000 + 7]), ch(iq[M * 2000 + 7:])])
     assert np.array_equal(got, ref)
-
-
-@pytest.mark.parametrize("tw,grid,frames", [(8, 0, 7001), (8, 3, 7001), (4, 5, 20000), (8, 1, 512 * 9), (8, 0, 300000)])
-def test_persistent_pairs_schedule_gives_identical_bits(oracle, tw, grid, frames):
-    """schedule 5: the wave pairs stay resident and walk tiles b, b+G, ...; the next tile's halo rows go HBM -> LDS
-    (global_load_lds) two steps ahead.  Small grids make every workgroup cross many tile boundaries; streams that are
-    not whole tiles, calls cut mid-tile and the int8 fallback (schedule 4) must all give the sliding kernel's bits."""
-    import torch
-    M, P = 64, 12
-    n = M * frames + 3
-    iq = synth.pulsed_iq_torch(n, 12, device="cuda")
-    h = oracle.design_prototype(M, P).astype(np.float32)
-    with Channelizer(M, taps=h, bit_width=12) as ch:
-        ch.set_option(L.PFB_OPT_SCHEDULE, 0)
-        ref = ch(iq).clone()
-        ch.reset()
-        ch.set_option(L.PFB_OPT_SCHEDULE, 5)
-        ch.set_option(L.PFB_OPT_TILE_WAVES, tw)
-        ch.set_option(L.PFB_OPT_GRID, grid)
-        cut = M * (frames // 3) + 7
-        got = torch.cat([ch(iq[:cut]), ch(iq[cut:])])
-        assert torch.equal(got, ref)
-    iq8 = synth.pulsed_iq_numpy(M * 3000, 8, np.int8, seed=3)
-    with Channelizer(M, taps=h, sample_format="int8", bit_width=8) as ch:
-        ch.set_option(L.PFB_OPT_SCHEDULE, 0)
-        ref8 = ch(iq8)
-        ch.reset()
-        ch.set_option(L.PFB_OPT_SCHEDULE, 5)
-        assert np.array_equal(ch(iq8), ref8)
 
 
 def test_page_locked_host_buffers_and_pipelined_staging():
@@ -786,33 +750,14 @@ def test_cpp_host_loop_without_python(oracle, tmp_path):
         assert len(pdws) == len(ref_pdws) > 0 and np.array_equal(pdws, ref_pdws)
 
 
-def test_fused_pdw_screen_probe_counts():
-    """pfb_probe_pdw_fused (schedule 12: the PDW screen inside the M=128 D=64 kernel's last pass -- a measurement, slower
-    than the separate pass): the output is the ordinary one and the candidates it parks are the
-    samples inside the bracket's float32 zone."""
-    import ctypes as C
-    import torch
+def test_removed_study_schedules_are_refused():
+    """schedules 1, 5, 10 and 12 were studies that lost (DESIGN.md sections 5 and 9); their numbers are not reused"""
     from sdr_channelizer_amd import design_prototype
-    M, P, D, n = 128, 12, 64, 1 << 22
-    iq = synth.pulsed_iq_torch(n, 12, device="cuda")
-    with Channelizer(M, taps=design_prototype(M, P), decimation=D, bit_width=12, fftshift=True) as ch:
-        want = ch(iq).clone()
-        m2 = want.real.float() ** 2 + want.imag.float() ** 2
-        med = m2.median(dim=0).values
-        thr = torch.stack([med * 0.97, med * 1.03, med * 900.0, med * 1100.0], dim=1).cpu().numpy().astype(np.float32)
-        y = torch.zeros_like(want)
-        ms, cnt = C.c_double(0.0), (C.c_uint64 * 3)()
-        rc = L.load().pfb_probe_pdw_fused(ch._h, C.c_void_p(iq.data_ptr()), n, C.c_void_p(y.data_ptr()), n // D,
-                                          thr.ctypes.data_as(C.POINTER(C.c_float)), 1, C.byref(ms), cnt)
-        assert rc == L.PFB_OK
-        assert torch.equal(y, want)
-        t = torch.from_numpy(thr).cuda()
-        zone = int(((m2 >= t[:, 0]) & (m2 <= t[:, 1])).sum())
-        band = int(((m2 >= t[:, 2]) & (m2 <= t[:, 3])).sum())
-        assert abs(int(cnt[0]) - zone) <= max(4, zone // 5000)   # fma vs mul + add at the zone's edges
-        assert abs(int(cnt[1]) - band) <= max(4, band // 1000)
-        assert cnt[2] == 0
-    with Channelizer(64, taps=design_prototype(64, 12)) as ch64:   # no fused instantiation
-        rc = L.load().pfb_probe_pdw_fused(ch64._h, C.c_void_p(iq.data_ptr()), 1 << 12, C.c_void_p(y.data_ptr()), 64,
-                                          thr.ctypes.data_as(C.POINTER(C.c_float)), 1, C.byref(ms), cnt)
-        assert rc == L.PFB_ERR_UNSUPPORTED
+    with Channelizer(64, taps=design_prototype(64, 12)) as ch:
+        for sched in (1, 5, 10, 12, 14):
+            with pytest.raises(L.PfbError):
+                ch.set_option(L.PFB_OPT_SCHEDULE, sched)
+        ch.set_option(L.PFB_OPT_SCHEDULE, 4)
+        with pytest.raises(L.PfbError):
+            ch.set_option(L.PFB_OPT_EXPERIMENT, 1 << 16)
+

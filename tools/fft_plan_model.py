@@ -119,6 +119,26 @@ PLANS = {
     "m10": (10, [5, 2], [2, 5], 10, 48, 64),
     "m20": (20, [10, 2], [2, 15], 42, 24, 64),
     "m40": (40, [8, 5], [5, 9], 45, 8, 64),
+    # the other plausible radio rates (pfb_kernels_mixed.hip); row strides from tools/fft_plan_search.py
+    "m12": (12, [6, 2], [2, 7], 38, 8, 64),
+    "m24": (24, [12, 2], [2, 13], 26, 8, 64),
+    "m25": (25, [5, 5], [5, 5], 25, 8, 64),
+    "m30": (30, [10, 3], [3, 13], 39, 8, 64),
+    "m48": (48, [16, 3], [3, 19], 57, 8, 64),
+    "m50": (50, [10, 5], [5, 11], 55, 8, 64),
+    "m80": (80, [16, 5], [5, 17], 101, 8, 64),
+    "m96": (96, [16, 6], [6, 17], 102, 8, 64),
+    "m100": (100, [10, 10], [10, 10], 106, 4, 64),
+    "m112": (112, [16, 7], [7, 17], 135, 8, 64),
+    "m120": (120, [12, 10], [10, 13], 138, 4, 64),
+    "m160": (160, [16, 10], [10, 17], 170, 8, 128),
+    "m200": (200, [10, 10, 2], [20, 20, 104], 210, 8, 256),
+    "m250": (250, [10, 5, 5], [25, 51, 50], 274, 4, 256),
+    "m280": (280, [7, 10, 4], [40, 28, 70], 296, 8, 320),
+    "m320": (320, [8, 10, 4], [40, 34, 84], 340, 8, 320),
+    "m400": (400, [10, 10, 4], [40, 40, 100], 424, 8, 448),
+    "m500": (500, [10, 10, 5], [50, 51, 102], 516, 4, 256),
+    "m512": (512, [16, 16, 2], [32, 33, 264], 528, 8, 256),
 }
 
 if __name__ == "__main__":
