@@ -236,6 +236,32 @@ int launch_frames(pfb_handle* h, const void* d_iq, uint64_t n, const void* hist,
     if (cm && !by_slabs)  // fused channel-major: 0 = sliding runs, 2 = tiles, 8 = short runs transposed in LDS, else the kernel's pick
       p.schedule = forced_fused ? h->opt_schedule : -1;
     if (p.schedule == 3 && h->opt_frames_per_block <= 0) fpb = 24;
+    // Team kernels run one workgroup per CU, so their runs are dealt in rounds of num_cus, and a last round that is not
+    // full costs a whole round: 683 593 frames of M = 1024 in the tuned 512-frame runs are 5.2 rounds = 6 (0.549 of the
+    // roofline), in 672-frame runs 3.97 rounds (0.600).  Unless the caller fixed it, the run length is the call's frames
+    // split evenly over k full rounds, k chosen for runs near twice the tuned length (full rounds of 1024-frame runs
+    // measured +1.3 % over 512: half the pipeline fills and drains) -- short calls thereby spread over every CU instead
+    // of filling a few.  (The slab route sizes its slabs as one 512-frame run per CU: already whole rounds.)
+    if (p.schedule == 6 && h->opt_frames_per_block <= 0 && !by_slabs && frames > 0) {
+      const long long slots = h->num_cus, target = 2ll * fpb;
+      const long long k = std::max<long long>(1, ((long long)frames + slots * target / 2) / (slots * target));
+      const long long even = ((long long)frames + k * slots - 1) / (k * slots);
+      fpb = (int)std::min<long long>(std::max<long long>(even, 2 * c), 4 * target);
+    }
+    // The other kernels with long runs (a wave pair, a lockstep workgroup or a single wave per run of 128-512 frames): a
+    // short call must not leave most of the chip idle -- 2 * 10^7 samples of M = 1024 in 512-frame runs kept 39 of 256 CUs
+    // busy (0.105 of the roofline; 0.456 spread over all of them).  When the tuned run length gives fewer runs than the
+    // chip holds at once, the runs shrink until it is full (at least one chunk pair each).
+    if ((p.schedule == 0 || p.schedule == 7 || p.schedule == 11 || p.schedule == 13) && h->opt_frames_per_block <= 0 && !by_slabs &&
+        !cm && frames > 0) {
+      const int waves = std::max(1, h->fast->threads / 64);
+      const long long per_cu = p.schedule == 7 ? 6 : p.schedule == 13 ? 2 : std::max(1, 8 / waves);  // runs resident per CU
+      const long long slots = h->num_cus * per_cu;
+      if (((long long)frames + fpb - 1) / fpb < slots) {
+        const long long even = ((long long)frames + slots - 1) / slots;
+        fpb = (int)std::min<long long>(fpb, std::max<long long>(2 * c, (even + c - 1) / c * c));
+      }
+    }
     if (p.schedule == 6 || p.schedule == 7) fpb = ((fpb + 2 * c - 1) / (2 * c)) * (2 * c);  // these kernels walk chunks in pairs
     if (p.schedule == 4) {
       if (h->opt_frames_per_block <= 0) fpb = 64;

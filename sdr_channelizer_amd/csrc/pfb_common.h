@@ -105,6 +105,7 @@ struct FastKernelInfo {
   int default_schedule;    // measured best schedule for this instantiation (PFB_OPT_SCHEDULE = -1)
   bool channel_major_ok;   // has a channel-major instantiation
   int magnitude_schedule;  // measured best schedule with PFB_FLAG_MAGNITUDE, -1 = default_schedule
+  int threads;             // threads of the plan's FIR workgroup (run-length policy for short calls)
 };
 const FastKernelInfo* find_fast_kernel(int M, int P, int D, int fmt, int variant = 0, bool channel_major = false);
 

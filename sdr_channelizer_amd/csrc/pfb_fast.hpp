@@ -356,6 +356,26 @@ struct FastCfg {
 
 // ---------------------------------------------------------------------------------
 
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD), each with its own L2.  mode 1:
+// consecutive runs go to ONE XCD (XCD x walks the x-th eighth of the stream): a run's halo rows are its predecessor's
+// last rows, read from that L2 -- eight sweeps through the stream.  mode G > 1: each XCD takes G consecutive runs at a
+// time, the eight XCDs 8 G consecutive runs: one window sweeping the stream, G - 1 of G halos still inside an XCD (the
+// blocks past the last whole group of 8 G stay where they are).  Bijective for any grid size.
+PFB_DEV long long xcd_remap_block(long long blk, long long nb, int mode) {
+  if (mode == 1) {
+    const long long q = nb >> 3, r = nb & 7, xc = blk & 7;
+    return (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (blk >> 3);
+  }
+  if (mode > 1) {
+    const long long G = mode, span = 8 * G, base = (blk / span) * span;
+    if (base + span <= nb) {
+      const long long in = blk - base;
+      return base + (in & 7) * G + (in >> 3);
+    }
+  }
+  return blk;
+}
+
 // CM = channel-major output, out[k * out_ld + out_frame0 + m] (MATLAB's column-major F x M): its own
 // instantiation, so the extra address arithmetic never costs the frame-major kernels a register.
 // MS = fused abs() with the magnitudes staged in LDS (its own instantiation of the sliding-run kernel, like CM)
@@ -873,10 +893,7 @@ struct FastKernel {
     // Consecutive runs go to one XCD (blocks are dealt round-robin over the 8 XCDs, so bid%8 labels
     // the XCD).  Bijective for any grid size.
     long long run = blockIdx.x;
-    if (p.xcd_remap) {
-      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
-      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
-    }
+    run = xcd_remap_block(run, gridDim.x, p.xcd_remap);
     const long long f_begin = run * p.frames_per_block;
     if (f_begin >= p.frames) return;
     const long long f_last = f_begin + p.frames_per_block;
@@ -1008,10 +1025,7 @@ struct FastKernel {
   template <int MAGSEL = -1>
   PFB_DEV void run_overlap(const KernelParams& p, float2* lds) {
     long long run = blockIdx.x;
-    if (p.xcd_remap) {
-      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
-      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
-    }
+    run = xcd_remap_block(run, gridDim.x, p.xcd_remap);
     const long long f_begin = run * p.frames_per_block;
     if (f_begin >= p.frames) return;
     const long long f_last = f_begin + p.frames_per_block;
@@ -1157,10 +1171,7 @@ struct FastKernel {
     Consts k;
     setup(p, wave < NT / 64 ? threadIdx.x : lane, k);  // FFT team: only the twiddles are used, rows `lane % S` of the passes' tables
     long long run = blockIdx.x;  // one run per workgroup, in dispatch order
-    if (p.xcd_remap) {  // consecutive runs on one XCD: a run's halo rows are its predecessor's last rows, still in that L2
-      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
-      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
-    }
+    run = xcd_remap_block(run, gridDim.x, p.xcd_remap);
     const long long f_begin = run * p.frames_per_block;
     if (f_begin >= p.frames) return;
     if (wave < NT / 64) {
@@ -1548,10 +1559,7 @@ struct FastKernel {
   PFB_DEV void run_twin(const KernelParams& p, float2* lds, float2* twl) {
     const long long G = gridDim.x, fpb = p.frames_per_block;
     long long r = blockIdx.x;
-    if (p.xcd_remap) {  // consecutive runs on one XCD: a run's halo rows are its predecessor's last rows
-      const long long q = G >> 3, rm = G & 7, xc = r & 7;
-      r = (xc < rm ? xc * (q + 1) : rm * (q + 1) + (xc - rm) * q) + (r >> 3);
-    }
+    r = xcd_remap_block(r, G, p.xcd_remap);
     const long long nruns = (p.frames + fpb - 1) / fpb;
     if (r >= nruns) return;
     // runs [r_lo, r_hi) are whole and have their halo inside `in`: the fast path; the others (the call's first run, a
@@ -1640,19 +1648,7 @@ struct FastKernel {
     static_assert(NT == 64, "one wave per run");
     const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
     long long blk = blockIdx.x;
-    if (p.xcd_remap == 1) {
-      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = blk & 7;
-      blk = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (blk >> 3);
-    } else if (p.xcd_remap > 1) {
-      // grouped remap: each XCD takes G consecutive blocks at a time (G = xcd_remap): one sweeping
-      // window for the whole chip, boundary halos still mostly on one XCD.  Tail blocks unmapped.
-      const long long G = p.xcd_remap, span = 8 * G, nb = gridDim.x;
-      const long long base = (blk / span) * span;
-      if (base + span <= nb) {
-        const long long in = blk - base, xc = in & 7, idx = in >> 3;
-        blk = base + xc * G + idx;
-      }
-    }
+    blk = xcd_remap_block(blk, gridDim.x, p.xcd_remap);
     const long long f_blk = blk * (long long)(NWV * L);
     const long long f_begin = f_blk + (long long)wave * L;
     Consts k;
@@ -1741,10 +1737,7 @@ struct FastKernel {
     const bool fir_role = wave < NPAIR;
     const int pair = fir_role ? wave : wave - NPAIR;
     long long blk = blockIdx.x;
-    if (p.xcd_remap) {
-      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = blk & 7;
-      blk = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (blk >> 3);
-    }
+    blk = xcd_remap_block(blk, gridDim.x, p.xcd_remap);
     const long long f_blk = blk * (long long)(NPAIR * L);
     const long long f_begin = f_blk + (long long)pair * L;
     float2* bufs = lds_fft + pair * 2 * K::BUF;
@@ -1822,10 +1815,7 @@ struct FastKernel {
     const bool fir_role = wave < NPAIR;
     const int pair = fir_role ? wave : wave - NPAIR;
     long long blk = blockIdx.x;
-    if (p.xcd_remap) {
-      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = blk & 7;
-      blk = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (blk >> 3);
-    }
+    blk = xcd_remap_block(blk, gridDim.x, p.xcd_remap);
     const long long f_begin = (blk * NPAIR + pair) * (long long)p.frames_per_block;
     const int nch = p.frames_per_block / C;  // even (host rounds); pairs past the end of the stream idle through the barriers
     float2* bufs = lds_fft + pair * 2 * K::BUF;
@@ -1876,10 +1866,7 @@ struct FastKernel {
     const int c0 = tid * CPT;
     const long long nchunks = (p.frames + C - 1) / C;
     long long tile = blockIdx.x;
-    if (p.xcd_remap) {
-      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = tile & 7;
-      tile = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (tile >> 3);
-    }
+    tile = xcd_remap_block(tile, gridDim.x, p.xcd_remap);
     const long long chunk = tile * NWV + wave;
     if (chunk >= nchunks) return;
     float2* lds = lds_all + wave * K::LDS_ELEMS;
@@ -1947,10 +1934,7 @@ struct FastKernel {
     static_assert((M * RL) % NTH == 0 && (RL & (RL - 1)) == 0 && RL % 32 == 0, "whole flush iterations over 32-frame blocks");
     const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
     long long tile = blockIdx.x;
-    if (p.xcd_remap) {
-      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = tile & 7;
-      tile = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (tile >> 3);
-    }
+    tile = xcd_remap_block(tile, gridDim.x, p.xcd_remap);
     const long long tf0 = tile * RL;
     if (tf0 >= p.frames) return;  // workgroup-uniform
     const long long f_begin = tf0 + (long long)wave * (CPW * C);
@@ -2154,10 +2138,7 @@ struct SegKernel {
   template <int MAGSEL = -1, int CMSEL = -1>
   PFB_DEV void run(const KernelParams& p, float2* lds) {
     long long run = blockIdx.x;
-    if (p.xcd_remap) {
-      const long long nb = gridDim.x, q = nb >> 3, r = nb & 7, xc = run & 7;
-      run = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (run >> 3);
-    }
+    run = xcd_remap_block(run, gridDim.x, p.xcd_remap);
     const long long f_begin = run * p.frames_per_block;
     if (f_begin >= p.frames) return;
     const long long l_seg = p.frames_per_block / SEG;  // host rounds frames_per_block to a multiple of C * SEG

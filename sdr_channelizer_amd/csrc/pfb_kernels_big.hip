@@ -59,11 +59,11 @@ static const FastEntry kRows[] = {
     entry<Cfg1024x16i16b>("pfb_fast<M1024,P16,D1024,int16,16w>", 256, 0),
     entry<Cfg1024x16i16>("pfb_fast<M1024,P16,D1024,int16,8w>", 256, 0),
     entry<Cfg560x12i16t>("pfb_fast<M560,P12,D560,int16>", 512, 6),
-    // 8-bit samples: the team plan spills 30 registers inside its chunk loop (18 % of roofline); the 9-wave lockstep
-    // plan does not (21 %) and is the default there
-    entry<Cfg560x12i8>("pfb_fast<M560,P12,D560,int8>", 252, 0),
+    // 8-bit samples: the team plan (spill-free since its loop issues the same memory operations on every path: 0.217 of
+    // the roofline) ahead of the 9-wave lockstep plan (0.180), which was the default while the team plan spilled 30 registers
+    entry<Cfg560x12i8t>("pfb_fast<M560,P12,D560,int8>", 512, 6),
     entry<Cfg560x12i16>("pfb_fast<M560,P12,D560,int16,9w>", 252, 0),
-    entry<Cfg560x12i8t>("pfb_fast<M560,P12,D560,int8,teams>", 512, 6),
+    entry<Cfg560x12i8>("pfb_fast<M560,P12,D560,int8,9w>", 252, 0),
     entry<Cfg560x12f32>("pfb_fast<M560,P12,D560,cf32>", 252, 0),
     entry<Cfg1024x16f32b>("pfb_fast<M1024,P16,D1024,cf32>", 256, 0),
     entry<Cfg1024x16i16d>("pfb_fast<M1024,P16,D1024,int16,duo>", 256, 13),

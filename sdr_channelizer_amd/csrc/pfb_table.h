@@ -12,7 +12,7 @@ template <class K>
 constexpr FastEntry entry(const char* name, int default_fpb, int default_schedule) {
   return FastEntry{K::M, K::P, K::D, K::FMT,
                    FastKernelInfo{&launch_fast<K>, &init_tables<K>, K::TAPS_LANE_FLOATS, K::TW_LANE_ELEMS, name, K::C,
-                                  default_fpb, K::CPT, default_schedule, kChannelMajorOk<K>, kMagnitudeSchedule<K>}};
+                                  default_fpb, K::CPT, default_schedule, kChannelMajorOk<K>, kMagnitudeSchedule<K>, K::NT}};
 }
 
 // small banks: SegKernel, 64 / M segments of the run per wave; frames_per_block is a multiple of C * SEG
@@ -20,7 +20,7 @@ template <class K>
 constexpr FastEntry seg_entry(const char* name, int default_fpb) {
   return FastEntry{K::M, K::P, K::D, K::FMT,
                    FastKernelInfo{&launch_seg<K>, &init_tables<K>, K::TAPS_LANE_FLOATS, K::TW_LANE_ELEMS, name,
-                                  SegKernel<K>::CT, default_fpb, 1, 0, true, -1}};
+                                  SegKernel<K>::CT, default_fpb, 1, 0, true, -1, 64}};
 }
 
 struct FastTablePart { const FastEntry* rows; int count; };

@@ -761,3 +761,29 @@ def test_removed_study_schedules_are_refused():
         with pytest.raises(L.PfbError):
             ch.set_option(L.PFB_OPT_EXPERIMENT, 1 << 16)
 
+
+
+@pytest.mark.parametrize("M,P,D,fmt,bw,tuned", [(1024, 16, 1024, "int16", 12, 512), (560, 12, 560, "int8", 8, 512), (56, 12, 56, "int16", 12, 512),
+                                               (8, 12, 8, "cf32", 1, 1024), (512, 12, 512, "int16", 12, 512), (320, 12, 320, "int16", 12, 256)])
+def test_default_run_length_follows_the_call_and_keeps_the_bits(M, P, D, fmt, bw, tuned):
+    """Unless PFB_OPT_FRAMES_PER_BLOCK fixes it, the run length of the long-run plans is chosen per call (pfb_api.cpp
+    launch_frames): whole rounds of the CUs for the team kernels, shorter runs when the tuned length would leave the chip
+    partly idle.  Which frames a workgroup computes never changes a bit: calls of very different lengths, also as a
+    stream of unequal calls, against the tuned length forced."""
+    import torch
+    from sdr_channelizer_amd import design_prototype
+    lens = [37, 5000, 683, 50001, 3 * tuned * 256 // 7]
+    n = sum(lens) * D + 5
+    if fmt == "cf32":
+        iq = torch.randn((n, 2), dtype=torch.float32, device="cuda")
+    else:
+        iq = synth.pulsed_iq_torch(n, bw, torch.int8 if fmt == "int8" else torch.int16, device="cuda")
+    kw = dict(taps=design_prototype(M, P), decimation=D, sample_format=fmt, bit_width=bw, fftshift=True)
+    with Channelizer(M, **kw) as a, Channelizer(M, **kw) as b:
+        b.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, tuned)
+        want = b(iq)
+        assert torch.equal(a(iq), want)
+        a.reset()
+        cuts = np.concatenate([[0], np.cumsum(lens) * D - 3, [n]])
+        parts = [a(iq[s:e]) for s, e in zip(cuts[:-1], cuts[1:])]
+        assert torch.equal(torch.cat([q for q in parts if q.numel()]), want)

@@ -1,4 +1,4 @@
-"""Summarise gpurun_out/prof_r02 (tools/profile_r02.sh): kernel stats of the default bench run, and per shape the HBM
+"""Summarise gpurun_out/prof_rNN (tools/profile_round.sh): kernel stats of the default bench run, and per shape the HBM
 traffic (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md 'HBM', WRITE_SIZE as is) and the issue-side
 counters of its channelizer kernel.  Writes <dir>/pmc_traffic.json for the headline kernel."""
 import csv
@@ -9,12 +9,12 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-ALG = {"cfg2": (1 << 30) * 12, "cfg3": (1 << 30) * 10, "cfg4": (1 << 30) * 12, "cfg5": (1 << 28) * 20,
-       "ref56": (1 << 28) * 12, "ref560": (1 << 28) * 12}
+ALG = {"cfg2": (1 << 30) * 12, "cfg1": (1 << 28) * 16, "cfg3": (1 << 30) * 10, "cfg4": (1 << 30) * 12, "cfg4_v3": (1 << 30) * 12,
+       "cfg5": (1 << 28) * 20, "ref56": (1 << 28) * 12, "ref560": (1 << 28) * 12}
 
 
 def channelizer_kernel(name):
-    return "pfb" in name and any(k in name for k in ("paired", "fast_kernel", "teams", "pairs_sliding", "seg_kernel", "tile", "overlap"))
+    return "pfb" in name and any(k in name for k in ("paired", "fast_kernel", "teams", "pairs_sliding", "seg_kernel", "tile", "overlap", "twin"))
 
 
 print("## default bench run under rocprofv3 --kernel-trace --stats")
@@ -36,7 +36,7 @@ traffic = {}
 for wl in ALG:
     acc = defaultdict(list)
     kname = None
-    for f in sorted(glob.glob(os.path.join(root, f"pmc_{wl}_*", "**", "*counter_collection.csv"), recursive=True)):
+    for f in sorted(glob.glob(os.path.join(root, f"pmc_{wl}_[0-9]", "**", "*counter_collection.csv"), recursive=True)):
         for row in csv.DictReader(open(f)):
             if channelizer_kernel(row["Kernel_Name"]):
                 kname = row["Kernel_Name"]
@@ -59,7 +59,7 @@ for wl in ALG:
                        traffic_over_algorithmic=tot / ALG[wl], counters={k: v for k, v in avg.items() if k.startswith("SQ_")})
 if "cfg2" in traffic:
     head = dict(what="HBM traffic of one launch of the headline kernel (cfg2, 2^30 samples) and of the other frame-major shapes: rocprofv3 PMC, "
-                     "FETCH_SIZE and WRITE_SIZE in separate --pmc passes (tools/profile_r02.sh)",
+                     "FETCH_SIZE and WRITE_SIZE in separate --pmc passes (tools/profile_round.sh)",
                 corrections="gfx950: FETCH_SIZE reports 1/2 of streamed read bytes (MI355X_MICROARCH.md 'HBM'): doubled; WRITE_SIZE as is; KB = 1024 B",
                 **{k: v for k, v in traffic["cfg2"].items() if k != "counters"}, shapes=traffic)
     json.dump(head, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
