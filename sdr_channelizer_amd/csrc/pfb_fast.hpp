@@ -90,6 +90,14 @@ PFB_DEV void fma_tap_hi(v2f& acc, v2f x, v2f h, int& tok) {
   (void)tok;
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(h));
 }
+// the first tap of a chain: acc = x * h + 0 with the zero as the instruction's inline constant -- the same operation on
+// the same values as an FMA into a zeroed register pair, without the v_mov_b64 that zeroed it (C per column and chunk)
+PFB_DEV void fma_tap0_lo(v2f& acc, v2f x, v2f h) {
+  asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(x), "v"(h));
+}
+PFB_DEV void fma_tap0_hi(v2f& acc, v2f x, v2f h) {
+  asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(acc) : "v"(x), "v"(h));
+}
 // The same FMAs as builtins: the broadcast is a shufflevector of the tap PAIR, which the backend folds into op_sel /
 // op_sel_hi (checked in the ISA: no v_mov, one v_pk_fma_f32 per tap).  Inline asm hides the instruction from the
 // scheduler: it clusters the FMAs of one accumulator, and on gfx950 the result of a packed-fp32 instruction cannot be read
@@ -771,15 +779,15 @@ struct FastKernel {
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) {
         v2f acc[C];  // C independent chains: tap-major order keeps dependent pk_fma's C issues apart
-#pragma unroll
-        for (int t = 0; t < C; ++t) acc[t] = (v2f){0.f, 0.f};
         int tok = 0;  // FMA ordering token (fma_tap_lo)
 #pragma unroll
         for (int q = 0; q < P; ++q) {
           const int j = ph + OS * q;
 #pragma unroll
           for (int t = 0; t < C; ++t) {
-            if (j & 1) fma_tap_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
+            if (q == 0 && (j & 1)) fma_tap0_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+            else if (q == 0) fma_tap0_lo(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+            else if (j & 1) fma_tap_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
             else fma_tap_lo(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
           }
         }
@@ -807,21 +815,56 @@ struct FastKernel {
   }
 
   // the two halves of fir_fft_store as separate steps (schedule F gives them to different waves)
+  // A thread's two adjacent columns c0, c0 + 1 are the adjacent branch outputs n0 = D-1-c0 (odd) and n0 - 1 (even) of
+  // a frame, and where pass 0's rows are unpadded (RS_0 = S_0) they are adjacent in LDS: ONE 16-byte write per frame
+  // instead of two 8-byte ones whose lanes sit 16 bytes apart (a 2-way bank conflict: 15 % of the M = 1024 team kernel's
+  // LDS cycles, 19 % at M = 560).
+  static constexpr bool kPairWrite = CPT == 2 && K::RS(0) == K::S(0) && K::S(0) % 2 == 0 && D % 2 == 0 && K::FS % 2 == 0 &&
+                                     K::BUF % 2 == 0;
   PFB_DEV void fir_to_lds(const Consts& k, const v2f (&x)[NW][CPT], float2* buf, int tid) {
+    if constexpr (kPairWrite) {
+#pragma unroll
+      for (int ph = 0; ph < OS; ++ph) {
+        v2f acc[2][C];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          int tok = 0;  // FMA ordering token (fma_tap_lo)
+#pragma unroll
+          for (int q = 0; q < P; ++q) {
+            const int j = ph + OS * q;
+#pragma unroll
+            for (int t = 0; t < C; ++t) {
+              if (q == 0 && (j & 1)) fma_tap0_hi(acc[cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+              else if (q == 0) fma_tap0_lo(acc[cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+              else if (j & 1) fma_tap_hi(acc[cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
+              else fma_tap_lo(acc[cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
+            }
+          }
+        }
+        if (!(K::LANES < NT) || tid < K::LANES) {
+#pragma unroll
+          for (int t = 0; t < C; ++t) {
+            const v2f lo = acc[1][t] * k.conj_mul, hi = acc[0][t] * k.conj_mul;  // positions n0 - 1, n0
+            *reinterpret_cast<float4*>(buf + t * K::FS + k.upos[ph][1]) = make_float4(lo.x, lo.y, hi.x, hi.y);
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int ph = 0; ph < OS; ++ph)
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) {
         v2f acc[C];
-#pragma unroll
-        for (int t = 0; t < C; ++t) acc[t] = (v2f){0.f, 0.f};
         int tok = 0;  // FMA ordering token (fma_tap_lo)
 #pragma unroll
         for (int q = 0; q < P; ++q) {
           const int j = ph + OS * q;
 #pragma unroll
           for (int t = 0; t < C; ++t) {
-            if (j & 1) fma_tap_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
+            if (q == 0 && (j & 1)) fma_tap0_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+            else if (q == 0) fma_tap0_lo(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+            else if (j & 1) fma_tap_hi(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
             else fma_tap_lo(acc[t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
           }
         }
@@ -920,8 +963,10 @@ struct FastKernel {
     for (int ph = 0; ph < OS; ++ph)
 #pragma unroll
       for (int cc = 0; cc < CPT; ++cc) {
+        if constexpr (kBuiltinFir) {
 #pragma unroll
-        for (int t = 0; t < C; ++t) acc[ph][cc][t] = (v2f){0.f, 0.f};
+          for (int t = 0; t < C; ++t) acc[ph][cc][t] = (v2f){0.f, 0.f};
+        }
         int tok = 0;  // FMA ordering token (fma_tap_lo)
 #pragma unroll
         for (int q = 0; q < P; ++q) {
@@ -932,7 +977,9 @@ struct FastKernel {
               if (j & 1) fma_tap_hi_b(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
               else fma_tap_lo_b(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
             } else {
-              if (j & 1) fma_tap_hi(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
+              if (q == 0 && (j & 1)) fma_tap0_hi(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+              else if (q == 0) fma_tap0_lo(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+              else if (j & 1) fma_tap_hi(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
               else fma_tap_lo(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
             }
           }
@@ -2107,14 +2154,13 @@ struct SegKernel {
           raw[t] = load<INTERIOR>(p, s_row0 + (c0 + C + (W - 1) + t) * D, f_seg + c0 + C + t);
       }
       v2f acc[C];
-#pragma unroll
-      for (int t = 0; t < C; ++t) acc[t] = (v2f){0.f, 0.f};
       int tok = 0;  // FMA ordering token (fma_tap_lo)
 #pragma unroll
       for (int q = 0; q < P; ++q)
 #pragma unroll
         for (int t = 0; t < C; ++t) {
-          if (q & 1) fma_tap_hi(acc[t], x[W - 1 + t - q], hp[q >> 1], tok);
+          if (q == 0) fma_tap0_lo(acc[t], x[W - 1 + t], hp[0]);
+          else if (q & 1) fma_tap_hi(acc[t], x[W - 1 + t - q], hp[q >> 1], tok);
           else fma_tap_lo(acc[t], x[W - 1 + t - q], hp[q >> 1], tok);
         }
       if (lane_on) {
