@@ -35,6 +35,12 @@ using Cfg560x12i16t =
     FastCfg<560, 12, 560, 2, PFB_FMT_INT16_IQ, 4, 3, 14, 10, 4, 40, 60, 140, 600, false, 3, false>;
 using Cfg560x12i8t =
     FastCfg<560, 12, 560, 2, PFB_FMT_INT8_IQ, 4, 3, 14, 10, 4, 40, 60, 140, 600, false, 3, false>;
+// the same teams on chunks of TWO frames: 5 FIR + 2 FFT waves, a 13-row window and 29 KB of LDS per workgroup, so that
+// TWO workgroups fit a CU (14 waves at <= 128 registers), neither synchronised with the other
+using Cfg560x12i16t2 =
+    FastCfg<560, 12, 560, 2, PFB_FMT_INT16_IQ, 2, 3, 14, 10, 4, 40, 60, 140, 600, false, 4, false>;
+using Cfg560x12i8t2 =
+    FastCfg<560, 12, 560, 2, PFB_FMT_INT8_IQ, 2, 3, 14, 10, 4, 40, 60, 140, 600, false, 4, false>;
 
 // complex float32 input at the training script's band count (generate_channelized_training_iq.m:95-100 channelizes data
 // that only exists as complex doubles in MATLAB's memory) and at cfg4's: the lockstep plans, whose one column per thread
@@ -58,11 +64,15 @@ static const FastEntry kRows[] = {
     entry<Cfg1024x16i16t>("pfb_fast<M1024,P16,D1024,int16>", 512, 6),
     entry<Cfg1024x16i16b>("pfb_fast<M1024,P16,D1024,int16,16w>", 256, 0),
     entry<Cfg1024x16i16>("pfb_fast<M1024,P16,D1024,int16,8w>", 256, 0),
-    entry<Cfg560x12i16t>("pfb_fast<M560,P12,D560,int16>", 512, 6),
-    // 8-bit samples: the team plan (spill-free since its loop issues the same memory operations on every path: 0.217 of
-    // the roofline) ahead of the 9-wave lockstep plan (0.180), which was the default while the team plan spilled 30 registers
-    entry<Cfg560x12i8t>("pfb_fast<M560,P12,D560,int8>", 512, 6),
+    // M = 560: teams on 2-frame chunks, two workgroups per CU (0.515 of the roofline against 0.476 for one 9-wave workgroup
+    // on 4-frame chunks, same process), then the 4-frame teams and the 9-wave lockstep plan
+    entry<Cfg560x12i16t2>("pfb_fast<M560,P12,D560,int16>", 512, 6),
+    entry<Cfg560x12i16t>("pfb_fast<M560,P12,D560,int16,4f>", 512, 6),
     entry<Cfg560x12i16>("pfb_fast<M560,P12,D560,int16,9w>", 252, 0),
+    // 8-bit samples: the same order (the 4-frame team plan, spill-free since its loop issues the same memory operations on
+    // every path, 0.217; the lockstep plan, the default while the team plan spilled 30 registers, 0.180)
+    entry<Cfg560x12i8t2>("pfb_fast<M560,P12,D560,int8>", 512, 6),
+    entry<Cfg560x12i8t>("pfb_fast<M560,P12,D560,int8,4f>", 512, 6),
     entry<Cfg560x12i8>("pfb_fast<M560,P12,D560,int8,9w>", 252, 0),
     entry<Cfg560x12f32>("pfb_fast<M560,P12,D560,cf32>", 252, 0),
     entry<Cfg1024x16f32b>("pfb_fast<M1024,P16,D1024,cf32>", 256, 0),

@@ -307,11 +307,11 @@ def test_fast_and_generic_kernels_agree():
     assert rel(fast, gen) < 2e-6
 
 
-@pytest.mark.parametrize("M,P,nvar", [(1024, 16, 4), (560, 12, 2)])
+@pytest.mark.parametrize("M,P,nvar", [(1024, 16, 4), (560, 12, 3)])
 def test_every_registered_plan_variant_matches_the_oracle(oracle, M, P, nvar):
     """PFB_OPT_VARIANT: the alternative fused plans kept for a shape (cfg4: the FIR-team / FFT-team kernel, 16 waves x
     1 column 8 x 8 x 16, 8 waves x 2 columns 16 x 16 x 4, independent 4-wave workgroups whose waves transform whole
-    frames; M = 560: teams, 9 waves in lockstep) all meet the fp32 tolerance, also on a stream that is not a whole number
+    frames; M = 560: teams on 2-frame chunks with two workgroups per CU, teams on 4-frame chunks, 9 waves in lockstep) all meet the fp32 tolerance, also on a stream that is not a whole number
     of workgroups; an index past the last registered plan is refused and leaves the handle usable."""
     n = M * 700 + 17
     iq = synth.pulsed_iq_numpy(n, 12, np.int16, seed=31)
@@ -358,6 +358,31 @@ def test_wave_frame_plan_gives_the_team_plan_s_bits(kw):
             ch.reset()
             cut = M * 611 + 3
             assert np.array_equal(np.concatenate([ch(iq[:cut]), ch(iq[cut:])]), ref), (fpb, grid, "two calls")
+
+
+@pytest.mark.parametrize("fmt,bw", [("int16", 12), ("int8", 8)])
+def test_m560_team_plans_give_the_same_bits(fmt, bw):
+    """M = 560: the default (teams on 2-frame chunks, two unsynchronised workgroups per CU) and variant 1 (one workgroup
+    per CU on 4-frame chunks) run the same taps in the same order through the same 14 x 10 x 4 passes: bit-identical, one
+    shot with a ragged tail, cut at an odd sample, several run lengths, with fftshift and fused abs()."""
+    M, P = 560, 12
+    n = M * 2100 + 7
+    iq = synth.pulsed_iq_numpy(n, bw, np.int8 if fmt == "int8" else np.int16, seed=78)
+    h = np.random.default_rng(4).standard_normal(M * P).astype(np.float32) / M
+    for kw in ({}, {"fftshift": True, "magnitude": True}):
+        with Channelizer(M, taps=h, sample_format=fmt, bit_width=bw, **kw) as ch:
+            ch.set_option(L.PFB_OPT_VARIANT, 1)
+            ref = ch(iq)
+            assert ch.last_kernel.endswith(",4f>")
+            ch.set_option(L.PFB_OPT_VARIANT, 0)
+            for fpb in (0, 4, 36, 512):
+                ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, fpb)
+                ch.reset()
+                assert np.array_equal(ch(iq), ref), (kw, fpb)
+                assert ch.last_kernel.endswith(fmt + ">")
+                ch.reset()
+                cut = M * 611 + 3
+                assert np.array_equal(np.concatenate([ch(iq[:cut]), ch(iq[cut:])]), ref), (kw, fpb, "two calls")
 
 
 @pytest.mark.parametrize("M,P,D,fmt,bw,P_fused", [(64, 8, 64, "int16", 12, 12), (64, 5, 64, "int8", 8, 12), (256, 6, 256, "int8", 8, 8),
