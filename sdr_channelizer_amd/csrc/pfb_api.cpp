@@ -243,8 +243,8 @@ int launch_frames(pfb_handle* h, const void* d_iq, uint64_t n, const void* hist,
     // measured +1.3 % over 512: half the pipeline fills and drains) -- short calls thereby spread over every CU instead
     // of filling a few.  (The slab route sizes its slabs as one 512-frame run per CU: already whole rounds.)
     if (p.schedule == 6 && h->opt_frames_per_block <= 0 && !by_slabs && frames > 0) {
-      // (a plan of <= 8 waves is built for two workgroups per CU: its rounds are twice as wide)
-      const long long slots = (long long)h->num_cus * ((h->fast->threads + 64 * c) <= 512 ? 2 : 1), target = 2ll * fpb;
+      // (plans of <= 8 waves are built for several workgroups per CU, 16 waves in all: their rounds are that much wider)
+      const long long slots = (long long)h->num_cus * std::max(1, 16 / ((h->fast->threads + 64 * c) / 64)), target = 2ll * fpb;
       const long long k = std::max<long long>(1, ((long long)frames + slots * target / 2) / (slots * target));
       const long long even = ((long long)frames + k * slots - 1) / (k * slots);
       fpb = (int)std::min<long long>(std::max<long long>(even, 2 * c), 4 * target);

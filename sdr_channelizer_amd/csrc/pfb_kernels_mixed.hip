@@ -49,6 +49,13 @@ using Cfg400x12i16 = FastCfg<400, 12, 400, 1, PFB_FMT_INT16_IQ, 8, 3, 10, 10, 4,
 using Cfg500x12i16 = FastCfg<500, 12, 500, 2, PFB_FMT_INT16_IQ, 4, 3, 10, 10, 5, 50, 51, 102, 516, false, 2, true>;
 using Cfg512x12i16 = FastCfg<512, 12, 512, 2, PFB_FMT_INT16_IQ, 8, 3, 16, 16, 2, 32, 33, 264, 528, false, 2, true>;
 
+// M = 250 / 500 as teams on 2-frame chunks, two columns per FIR thread: 4 / 6 waves per workgroup, so that four / two
+// unsynchronised workgroups fit a CU (what took M = 560 from 0.476 to 0.515): 0.398 -> 0.502 and 0.409 -> 0.516, the
+// defaults.  The same plan lost on 200 (0.380 vs 0.386), 280 (0.370 vs 0.422), 320 (0.407 vs 0.460), 400 (0.426 vs
+// 0.497) and 512 (0.438 vs 0.497) against their 8-frame teams / lockstep plans: profiles/r03_mixed_radix_two_frame_teams.txt
+using Cfg250x12i16t2 = FastCfg<250, 12, 250, 2, PFB_FMT_INT16_IQ, 2, 3, 10, 5, 5, 25, 51, 50, 274, false, 4, false>;
+using Cfg500x12i16t2 = FastCfg<500, 12, 500, 2, PFB_FMT_INT16_IQ, 2, 3, 10, 10, 5, 50, 51, 102, 516, false, 4, false>;
+
 static const FastEntry kRows[] = {
     // default run lengths and schedules: the best of tools/mixed_probe.py's sweep (profiles/r03_mixed_radix_shapes.txt);
     // the three-pass shapes also have the FIR-team / FFT-team instantiation (schedule 6), the default where it won
@@ -65,11 +72,13 @@ static const FastEntry kRows[] = {
     entry<Cfg120x12i16>("pfb_fast<M120,P12,D120,int16>", 512, 7),
     entry<Cfg160x12i16>("pfb_fast<M160,P12,D160,int16>", 128, 0),
     entry<Cfg200x12i16>("pfb_fast<M200,P12,D200,int16>", 256, 0),
-    entry<Cfg250x12i16>("pfb_fast<M250,P12,D250,int16>", 256, 0),
+    entry<Cfg250x12i16t2>("pfb_fast<M250,P12,D250,int16>", 512, 6),
+    entry<Cfg250x12i16>("pfb_fast<M250,P12,D250,int16,lockstep>", 256, 0),
     entry<Cfg280x12i16>("pfb_fast<M280,P12,D280,int16>", 256, 6),
     entry<Cfg320x12i16>("pfb_fast<M320,P12,D320,int16>", 256, 6),
     entry<Cfg400x12i16>("pfb_fast<M400,P12,D400,int16>", 256, 6),
-    entry<Cfg500x12i16>("pfb_fast<M500,P12,D500,int16>", 128, 0),
+    entry<Cfg500x12i16t2>("pfb_fast<M500,P12,D500,int16>", 512, 6),
+    entry<Cfg500x12i16>("pfb_fast<M500,P12,D500,int16,lockstep>", 128, 0),
     entry<Cfg512x12i16>("pfb_fast<M512,P12,D512,int16>", 512, 0),
 };
 
