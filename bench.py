@@ -48,7 +48,7 @@ WORKLOADS = {
 # what the default N = 1 run times after the headline: (workload, channel_major)
 OTHER_WORKLOADS = [("cfg1", False), ("cfg3", False), ("cfg4", False), ("cfg5", False), ("ref56", False), ("ref560", False),
                    ("cfg2", True), ("cfg3", True), ("cfg4", True), ("cfg5", True)]
-TRAFFIC_SOURCE = "profiles/r02_pmc_traffic.json"  # rocprofv3 --pmc passes of this command (never measured in-run)
+TRAFFIC_SOURCE = "profiles/r03_pmc_traffic.json"  # rocprofv3 --pmc passes of this command (never measured in-run)
 
 
 def parse_args():

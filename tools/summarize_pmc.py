@@ -50,10 +50,12 @@ for wl in ALG:
     print(f"  {wl}: {kname[:70] if kname else ''}")
     print(f"     HBM read {rd / 1e9:8.3f} GB  write {wr / 1e9:8.3f} GB  total {tot / 1e9:8.3f} GB = {tot / ALG[wl]:.3f} x algorithmic ({ALG[wl] / 1e9:.3f} GB)")
     if "SQ_LDS_IDX_ACTIVE" in avg:
+        # SQ_BUSY_CYCLES is summed over the 32 shader engines, SQ_ACTIVE_INST_VALU counts wave instructions (4 issue cycles
+        # each on one of 1024 SIMDs): VALU issue share = 4 INST / (1024 BUSY / 32) = INST / (8 BUSY)
         print("     LDS bank-conflict cycles / LDS-active cycles = {:.3f};  WAIT_INST_ANY / WAVE_CYCLES = {:.3f};  WAIT_ANY / WAVE_CYCLES = {:.3f};  "
-              "ACTIVE_INST_VALU / (4 x BUSY_CYCLES) ~ VALU busy = {:.3f}".format(
+              "VALU issue share = ACTIVE_INST_VALU / (8 x BUSY_CYCLES) = {:.3f}".format(
                   avg["SQ_LDS_BANK_CONFLICT"] / max(avg["SQ_LDS_IDX_ACTIVE"], 1), avg["SQ_WAIT_INST_ANY"] / avg["SQ_WAVE_CYCLES"],
-                  avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"], avg["SQ_ACTIVE_INST_VALU"] / (4.0 * avg["SQ_BUSY_CYCLES"])))
+                  avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"], avg["SQ_ACTIVE_INST_VALU"] / (8.0 * avg["SQ_BUSY_CYCLES"])))
     traffic[wl] = dict(kernel=kname, FETCH_SIZE_KB=avg.get("FETCH_SIZE"), WRITE_SIZE_KB=avg.get("WRITE_SIZE"), hbm_read_bytes_per_launch=rd,
                        hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=tot, algorithmic_bytes_per_launch=ALG[wl],
                        traffic_over_algorithmic=tot / ALG[wl], counters={k: v for k, v in avg.items() if k.startswith("SQ_")})
