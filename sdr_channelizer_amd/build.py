@@ -44,7 +44,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     objs = []
     bdir = os.path.join(PKG, "build")
     os.makedirs(bdir, exist_ok=True)
-    common = ["-O3", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+    common = ["-O3", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"] + os.environ.get("PFB_EXTRA_CXXFLAGS", "").split()
     jobs = []
     hdr_time = max(os.path.getmtime(h) for h in [os.path.join(CSRC, f) for f in HEADERS] +
                    [os.path.join(ROOT, "include", f) for f in PUBLIC_HEADERS])

@@ -21,11 +21,11 @@ namespace pfb {
 
 //                 M    P   D  CPT FMT               C NP R0 R1 R2 RS0 RS1 RS2 FS  PP     MINW  TW_TABLE
 using Cfg12x12i16 = FastCfg<12, 12, 12, 1, PFB_FMT_INT16_IQ, 8, 2, 6, 2, 1, 2, 7, 0, 38, true, 3>;
-using Cfg24x12i16 = FastCfg<24, 12, 24, 1, PFB_FMT_INT16_IQ, 8, 2, 12, 2, 1, 2, 13, 0, 26, true, 3>;
+using Cfg24x12i16 = FastCfg<24, 12, 24, 1, PFB_FMT_INT16_IQ, 8, 2, 12, 2, 1, 2, 13, 0, 26, true, 4>;
 // (M = 25: 5 x 5 leaves the final pass 5-channel = 40-byte store runs; 0.34-0.39 of roofline -- another frame stride,
 // chunks of 16 frames per segment: no better)
 using Cfg25x12i16 = FastCfg<25, 12, 25, 1, PFB_FMT_INT16_IQ, 8, 2, 5, 5, 1, 5, 5, 0, 25, true, 3>;
-using Cfg30x12i16 = FastCfg<30, 12, 30, 1, PFB_FMT_INT16_IQ, 8, 2, 10, 3, 1, 3, 13, 0, 39, true, 3>;
+using Cfg30x12i16 = FastCfg<30, 12, 30, 1, PFB_FMT_INT16_IQ, 8, 2, 10, 3, 1, 3, 13, 0, 39, true, 4>;
 // M = 48 / 50 as ordinary single-wave plans (48 / 50 of 64 lanes own a column, like M = 56): 0.52 / 0.53 against
 // 0.37 / 0.46 as one-segment SegKernel shapes
 using Cfg48x12i16 = FastCfg<48, 12, 48, 1, PFB_FMT_INT16_IQ, 8, 2, 16, 3, 1, 3, 19, 0, 57, false, 4>;
@@ -39,7 +39,7 @@ using Cfg120x12i16 = FastCfg<120, 12, 120, 2, PFB_FMT_INT16_IQ, 4, 2, 12, 10, 1,
 // (M = 160 with 4 columns per lane on one wave needs 256 registers and still spills: 2 columns, two waves in lockstep)
 using Cfg160x12i16 = FastCfg<160, 12, 160, 2, PFB_FMT_INT16_IQ, 8, 2, 16, 10, 1, 10, 17, 0, 170, false, 2, true>;
 
-using Cfg200x12i16 = FastCfg<200, 12, 200, 1, PFB_FMT_INT16_IQ, 8, 3, 10, 10, 2, 20, 20, 104, 210, false, 2, true>;
+using Cfg200x12i16 = FastCfg<200, 12, 200, 1, PFB_FMT_INT16_IQ, 8, 3, 10, 10, 2, 20, 20, 104, 210, false, 4, true>;
 using Cfg250x12i16 = FastCfg<250, 12, 250, 1, PFB_FMT_INT16_IQ, 4, 3, 10, 5, 5, 25, 51, 50, 274, false, 2, true>;
 using Cfg280x12i16 = FastCfg<280, 12, 280, 1, PFB_FMT_INT16_IQ, 8, 3, 7, 10, 4, 40, 28, 70, 296, false, 2, true>;
 // (M = 320 as 16 x 10 x 2: 0.37 -- the FFT team's two passes then use 20 and 32 of a wave's 64 lanes; 8 x 10 x 4: 40 and 32)
@@ -67,7 +67,7 @@ static const FastEntry kRows[] = {
     entry<Cfg50x12i16>("pfb_fast<M50,P12,D50,int16>", 256, 7),
     entry<Cfg80x12i16>("pfb_fast<M80,P12,D80,int16>", 256, 0),
     entry<Cfg96x12i16>("pfb_fast<M96,P12,D96,int16>", 256, 0),
-    entry<Cfg100x12i16>("pfb_fast<M100,P12,D100,int16>", 128, 0),
+    entry<Cfg100x12i16>("pfb_fast<M100,P12,D100,int16>", 256, 7),
     entry<Cfg112x12i16>("pfb_fast<M112,P12,D112,int16>", 128, 0),
     entry<Cfg120x12i16>("pfb_fast<M120,P12,D120,int16>", 512, 7),
     entry<Cfg160x12i16>("pfb_fast<M160,P12,D160,int16>", 128, 0),
