@@ -13,10 +13,10 @@ from sdr_channelizer_amd import _lib as L  # noqa: E402
 
 # (M, P, D, formats, schedules worth forcing besides the default)
 SHAPES = [
-    (64, 12, 64, ("int16", "int8", "cf32"), (0, 2, 3, 4, 5, 7, 8)),
+    (64, 12, 64, ("int16", "int8", "cf32"), (0, 2, 3, 4, 7, 8, 11)),
     (64, 16, 64, ("int16",), (0, 4, 7, 8)),
-    (128, 12, 64, ("int16", "cf32"), (0, 2, 3, 7, 8)),
-    (256, 8, 256, ("int8", "int16", "cf32"), (0, 2, 8)),
+    (128, 12, 64, ("int16", "cf32"), (0, 2, 3, 7, 8, 11)),
+    (256, 8, 256, ("int8", "int16", "cf32"), (0, 2, 8, 11)),
     (1024, 16, 1024, ("int16", "cf32"), (0, 6)),
     (56, 12, 56, ("int16", "int8", "cf32"), (0, 2, 3, 7, 8)),
     (560, 12, 560, ("int16", "int8", "cf32"), (0, 6)),
