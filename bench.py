@@ -254,6 +254,29 @@ def main() -> None:
         else:
             ch(iq, out=out, sync=False)
 
+    halo_mode = args.halo
+    if world > 1:
+        # One probing step before anything is timed: if the neighbour exchange (ncclSend / ncclRecv) fails on ANY rank -- the
+        # callback reports it, the step returns PFB_ERR_COMM -- every rank falls back to the all_gather form of the same
+        # exchange, and the line says so.  (PFB_BENCH_FAIL_P2P=1 injects the failure: how the fallback is rehearsed.)
+        failed = 0
+        try:
+            if os.environ.get("PFB_BENCH_FAIL_P2P") and args.halo == "p2p":
+                raise L.PfbError(L.PFB_ERR_COMM, "injected")
+            step()
+            ch.sync()
+        except L.PfbError as e:
+            print(f"[rank {rank}] halo exchange ({args.halo}) failed: {e}", file=sys.stderr)
+            failed = 1
+        flag = torch.tensor([failed], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) and args.halo == "p2p":
+            halo_mode = "allgather"
+            ch.reset()
+            ch.attach_shard(rank, world, make_exchange(rank, world, None, halo_mode, local_rank), ring=True)
+        elif int(flag.item()):
+            raise SystemExit("halo exchange failed")
+
     # The first ~15 launches after an idle GPU run 3-25 % slow (clock ramp).  If the caller asks
     # for fewer warm-up steps than that, run the difference as extra untimed steps first; the W warm-up steps and the
     # K timed steps that follow are exactly what was asked for.
@@ -310,7 +333,7 @@ def main() -> None:
             n4 = 1 << l2
             c4, _ = make_handle("cfg4", False, tuned=False)
             iq4, out4 = make_buffers("cfg4", l2, False, start=rank * n4)
-            c4.attach_shard(rank, world, make_exchange(rank, world, None, args.halo, local_rank), ring=True)
+            c4.attach_shard(rank, world, make_exchange(rank, world, None, halo_mode, local_rank), ring=True)
             out4 = out4.reshape(-1)[: (n4 // c4D) * c4M].reshape(n4 // c4D, c4M)
             halo4 = c4.halo_samples
             for _ in range(6):
@@ -337,7 +360,7 @@ def main() -> None:
             k_all = [v[0] for v in g]
             wall_max = max(v[1] for v in g)
             b4 = c4bytes + 8 * (c4M // c4D)
-            sharded_cfg4 = {"workload": "cfg4", "layout": "frame-major", "sharded": f"time-sharded x{world} (ring), {args.backend} ({args.halo})",
+            sharded_cfg4 = {"workload": "cfg4", "layout": "frame-major", "sharded": f"time-sharded x{world} (ring), {args.backend} ({halo_mode})",
                             "shape": f"M={c4M} P={c4P} D={c4D} {c4fmt}, 2^{l2} samples per GPU per step", "kernel": kname4,
                             "halo_samples": int(halo4), "halo_bytes": int(halo4 * c4bytes), "launches_per_step": 2, "steps": k4,
                             "kernel_ms_per_rank": {"min": round(min(k_all), 4), "max": round(max(k_all), 4),
@@ -375,7 +398,7 @@ def main() -> None:
                         "default (4: FIR/FFT wave pairs, 8x64-frame workgroups)" if M == 64 else "default for the shape (DESIGN.md section 5.2)"),
                        "samples_per_gpu": n, "prewarm_steps": prewarm,
                        "parallelism": (f"time-sharded x{world}: one stream, rank r owns samples [r*n, (r+1)*n); halo {halo} raw samples "
-                                       f"({halo * bytes_in} B) per rank per step over {args.backend} ({args.halo}) on a side stream, "
+                                       f"({halo * bytes_in} B) per rank per step over {args.backend} ({halo_mode}{' after p2p failed' if halo_mode != args.halo else ''}) on a side stream, "
                                        f"interior frames first") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -55,3 +55,14 @@ def test_two_ranks_start_themselves_and_print_one_line(halo):
     assert c4["halo_bytes"] == 61440 and c4["halo_samples"] == 15360 and c4["launches_per_step"] == 2
     assert len(c4["kernel_ms_per_rank"]["all"]) == 2 and c4["kernel_ms_per_rank"]["min"] > 0 and c4["step_wall_ms"] > 0
     assert c4["kernel"].startswith("pfb_fast<M1024,P16") and c4["ms_value"] > 0
+
+
+@pytest.mark.timeout(400)
+def test_two_ranks_fall_back_to_the_collective_when_the_neighbour_exchange_fails():
+    """bench.py probes one sharded step before it times anything; a failed point-to-point exchange on any rank (injected
+    here) switches every rank to the all_gather form of the same exchange, and the line says so."""
+    d = run_bench(["--gpus", "2", "--backend", "gloo", "--halo", "p2p", "--log2-samples", "24", "--steps", "3", "--warmup", "2",
+                   "--no-other-workloads"],
+                  env_extra={"PFB_BENCH_ONE_DEVICE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "PFB_BENCH_FAIL_P2P": "1"})
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "allgather after p2p failed" in d["config"]["parallelism"]
