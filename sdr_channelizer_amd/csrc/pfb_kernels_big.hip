@@ -60,6 +60,8 @@ using Cfg1024x16i16q =
 using Cfg1024x16i16d =
     FastCfg<1024, 16, 1024, 4, PFB_FMT_INT16_IQ, 8, 3, 16, 16, 4, 64, 68, 260, 1088, false, 2, true, true>;
 
+// (M = 560 on schedule 13 -- 5 waves per workgroup, chunks of 5 frames, one frame per wave, 124 registers, three workgroups
+// per CU -- is bit-identical to the team plans and slower: 0.37-0.39 of the roofline against 0.524 in one process; removed)
 static const FastEntry kRows[] = {
     entry<Cfg1024x16i16t>("pfb_fast<M1024,P16,D1024,int16>", 512, 6),
     entry<Cfg1024x16i16b>("pfb_fast<M1024,P16,D1024,int16,16w>", 256, 0),
