@@ -2451,7 +2451,7 @@ hipError_t launch_fast(const KernelParams& p, hipStream_t s) {
       constexpr size_t kPair = sizeof(float2) * 2 * K::BUF;
       // (workgroups of ONE or TWO pairs -- a barrier that couples 2 or 4 waves, 8 or 4 workgroups per CU -- measured: cfg2
       // 0.61-0.65 against 0.72 for its 8 halo-sharing pairs, M = 56 0.58-0.61 against 0.62, cfg5 0.44-0.49 against 0.68;
-      // profiles/r03_tiny_pair_workgroups_ab.txt)
+      // profiles/r03_tiny_pair_workgroups_ab.txt; four pairs at two workgroups per CU: M = 56 0.575-0.605 against 0.608)
       if (p.tile_waves == 4) return launch_pairs_sliding<K, 4, 2>(p, s);
       if constexpr (K::MIN_WAVES >= 4 && 8 * kPair <= 160 * 1024) {
         if (p.tile_waves >= 8) return launch_pairs_sliding<K, 8, 4>(p, s);
