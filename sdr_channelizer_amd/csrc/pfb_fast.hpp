@@ -50,6 +50,8 @@
 
 #include "pfb_common.h"
 
+#include <utility>
+
 namespace pfb {
 
 // ---------------------------------------------------------------------------------
@@ -393,6 +395,10 @@ struct FastKernel {
   using raw_t = typename ST::raw_t;
   static constexpr int M = K::M, P = K::P, D = K::D, CPT = K::CPT, C = K::C, W = K::W, OS = K::OS, NT = K::NT;
   static constexpr int NW = W - 1 + C;  // window rows held in registers during a chunk
+  // the window as a RING of NWP rows (NW rounded up to whole chunks): after PERIOD chunks every row is back in its
+  // register, so a chunk loop unrolled PERIOD times indexes the window with compile-time constants and never moves it
+  static constexpr int NWP = (NW + C - 1) / C * C, PERIOD = NWP / C;
+  static constexpr bool kRingOk = PERIOD >= 2 && PERIOD <= 4;
 
   struct alignas(sizeof(raw_t) * CPT) RawVec { raw_t v[CPT]; };
 
@@ -931,6 +937,8 @@ struct FastKernel {
     }
   }
 
+  // (The same loop with the window as a ring -- PERIOD chunks per iteration, no slide, see run_overlap_ring -- measured on
+  // cfg3: 0.676-0.686 either way at 24- and 36-frame runs; not kept here.)
   template <int MAGSEL = -1>
   PFB_DEV void run(const KernelParams& p, float2* lds) {
     // Consecutive runs go to one XCD (blocks are dealt round-robin over the 8 XCDs, so bid%8 labels
@@ -958,7 +966,11 @@ struct FastKernel {
   // with the next chunk's FMAs; the branch outputs wait in registers and go to LDS after pass 1.  Rows are fetched two
   // chunks ahead instead of one.  Same arithmetic per output as schedule A: bit-identical.
   static constexpr bool kBuiltinFir = OS == 2 && CPT == 1;  // cfg5's shape: no spills with the scheduler-visible FMAs (see fma_tap_lo_b)
-  PFB_DEV void fir_compute(const Consts& k, const v2f (&x)[NW][CPT], v2f (&acc)[OS][CPT][C]) {
+  // (PH / NX: the window as a ring of NX rows -- logical row i is x[(i + C PH) % NX] -- for run_overlap_ring; the sliding
+  // callers pass the NW logical rows themselves, PH = 0)
+  template <int PH = 0, int NX = NW>
+  PFB_DEV void fir_compute(const Consts& k, const v2f (&xw)[NX][CPT], v2f (&acc)[OS][CPT][C]) {
+    auto x = [&](int i) -> const v2f (&)[CPT] { return xw[(i + C * PH) % NX]; };
 #pragma unroll
     for (int ph = 0; ph < OS; ++ph)
 #pragma unroll
@@ -974,13 +986,13 @@ struct FastKernel {
 #pragma unroll
           for (int t = 0; t < C; ++t) {
             if constexpr (kBuiltinFir) {
-              if (j & 1) fma_tap_hi_b(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
-              else fma_tap_lo_b(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
+              if (j & 1) fma_tap_hi_b(acc[ph][cc][t], x(W - 1 + t - j)[cc], k.hp[j >> 1][cc]);
+              else fma_tap_lo_b(acc[ph][cc][t], x(W - 1 + t - j)[cc], k.hp[j >> 1][cc]);
             } else {
-              if (q == 0 && (j & 1)) fma_tap0_hi(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
-              else if (q == 0) fma_tap0_lo(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc]);
-              else if (j & 1) fma_tap_hi(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
-              else fma_tap_lo(acc[ph][cc][t], x[W - 1 + t - j][cc], k.hp[j >> 1][cc], tok);
+              if (q == 0 && (j & 1)) fma_tap0_hi(acc[ph][cc][t], x(W - 1 + t - j)[cc], k.hp[j >> 1][cc]);
+              else if (q == 0) fma_tap0_lo(acc[ph][cc][t], x(W - 1 + t - j)[cc], k.hp[j >> 1][cc]);
+              else if (j & 1) fma_tap_hi(acc[ph][cc][t], x(W - 1 + t - j)[cc], k.hp[j >> 1][cc], tok);
+              else fma_tap_lo(acc[ph][cc][t], x(W - 1 + t - j)[cc], k.hp[j >> 1][cc], tok);
             }
           }
         }
@@ -1069,6 +1081,62 @@ struct FastKernel {
     pass<1, INTERIOR, MAGSEL>(p, cur, nullptr, tid, f_begin + (nchunks - 1) * C, k.tw);
   }
 
+  // The same pipeline over a run of exactly PERIOD = NWP / C chunks with the window as a RING of NWP = NW rounded up to
+  // whole chunks: the chunk loop is gone (PERIOD straight-line steps, every window index a compile-time constant), and so
+  // are the W-1 register moves per column that slide the window after every chunk (62 of the 499 VALU instructions of
+  // the cfg5 chunk loop).  Same taps, same order: bit-identical.  Interior runs only; any other run takes the loop above.
+  template <int MAGSEL>
+  PFB_DEV void run_overlap_ring(const KernelParams& p, const Consts& k, float2* lds, long long f_begin) {
+    static_assert(NT == 64 && K::NP == 2 && !K::PINGPONG, "single-wave two-pass plans");
+    const int tid = threadIdx.x;
+    const int c0 = tid * CPT;
+    const raw_t* run_ptr = static_cast<const raw_t*>(p.in) + ((f_begin - (W - 1)) * D + p.base);
+    v2f x[NWP][CPT];
+    raw_t raw[C][CPT];
+    v2f acc[OS][CPT][C];
+#pragma unroll
+    for (int i = 0; i < W - 1; ++i) {
+      raw_t t[CPT];
+      load_row<true>(p, run_ptr, f_begin - (W - 1) + i, i, c0, t);
+#pragma unroll
+      for (int cc = 0; cc < CPT; ++cc) x[i][cc] = cvt(t[cc]);
+    }
+    auto load_chunk_rows = [&](int ci) {
+#pragma unroll
+      for (int t = 0; t < C; ++t) load_row<true>(p, run_ptr, f_begin + ci * C + t, W - 1 + ci * C + t, c0, raw[t]);
+    };
+    auto take_rows = [&]<int PH>() {  // the rows of chunk PH: logical rows W-1 ... W-2+C of phase PH
+#pragma unroll
+      for (int t = 0; t < C; ++t)
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) x[(W - 1 + t + C * PH) % NWP][cc] = cvt(raw[t][cc]);
+    };
+    load_chunk_rows(0);
+    take_rows.template operator()<0>();
+    load_chunk_rows(1);
+    fir_compute<0, NWP>(k, x, acc);
+    fir_write(k, acc, lds, tid);
+    team_sync<true>();
+    float2* cur = lds;
+    float2* nxt = lds + K::BUF;
+    take_rows.template operator()<1>();
+    auto step = [&]<int CI>() {  // chunk CI's FFT next to chunk CI + 1's FIR
+      if constexpr (CI + 2 < PERIOD) load_chunk_rows(CI + 2);
+      fir_compute<CI + 1, NWP>(k, x, acc);
+      pass<0>(p, cur, cur, tid, f_begin + CI * C, k.tw);
+      team_sync<true>();
+      pass<1, true, MAGSEL>(p, cur, nullptr, tid, f_begin + CI * C, k.tw);
+      fir_write(k, acc, nxt, tid);
+      team_sync<true>();
+      float2* t = cur; cur = nxt; nxt = t;
+      if constexpr (CI + 2 < PERIOD) take_rows.template operator()<CI + 2>();
+    };
+    [&]<int... CI>(std::integer_sequence<int, CI...>) { (step.template operator()<CI>(), ...); }(std::make_integer_sequence<int, PERIOD - 1>{});
+    pass<0>(p, cur, cur, tid, f_begin + (PERIOD - 1) * C, k.tw);
+    team_sync<true>();
+    pass<1, true, MAGSEL>(p, cur, nullptr, tid, f_begin + (PERIOD - 1) * C, k.tw);
+  }
+
   template <int MAGSEL = -1>
   PFB_DEV void run_overlap(const KernelParams& p, float2* lds) {
     long long run = blockIdx.x;
@@ -1080,6 +1148,12 @@ struct FastKernel {
     Consts k;
     setup(p, threadIdx.x, k);
     const bool interior = p.vec_ok && ((f_begin - (W - 1)) * D + p.base >= 0) && (f_last <= p.frames);
+    if constexpr (kRingOk) {
+      if (interior && p.frames_per_block == C * PERIOD) {
+        run_overlap_ring<MAGSEL>(p, k, lds, f_begin);
+        return;
+      }
+    }
     if (interior) run_overlap_impl<true, MAGSEL>(p, k, lds, f_begin, f_end);
     else run_overlap_impl<false, MAGSEL>(p, k, lds, f_begin, f_end);
   }

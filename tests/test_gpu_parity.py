@@ -684,7 +684,9 @@ def test_pairs_over_sliding_runs_give_identical_bits(M, P, D, fmt, bw, pairs):
                                           (64, 12, 64, "int8", 8), (64, 16, 64, "int16", 12)])
 def test_software_pipelined_runs_give_identical_bits(M, P, D, fmt, bw):
     """schedule 11: sliding runs with the next chunk's FIR scheduled into this chunk's FFT (two LDS chunk buffers, rows two
-    chunks ahead): runs of one chunk, runs that end mid-chunk, calls cut mid-frame -- the bits of schedule 0."""
+    chunks ahead): runs of one chunk, runs that end mid-chunk, calls cut mid-frame -- the bits of schedule 0.  Runs of exactly
+    one PERIOD of chunks (12, 24 or 32 frames depending on the shape) take the straight-line variant whose window is a ring
+    of registers that never moves (run_overlap_ring); with fused abs() too."""
     n = D * 5003 + 11
     iq = synth.pulsed_iq_numpy(n, bw, np.int8 if fmt == "int8" else np.int16, seed=19)
     h = np.random.default_rng(14).standard_normal(M * P).astype(np.float32) / M
@@ -692,13 +694,22 @@ def test_software_pipelined_runs_give_identical_bits(M, P, D, fmt, bw):
         ch.set_option(L.PFB_OPT_SCHEDULE, 0)
         ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, 512)
         ref = ch(iq)
-        for fpb in (8, 32, 52, 512):
+        for fpb in (8, 12, 24, 32, 52, 512):
             ch.reset()
             ch.set_option(L.PFB_OPT_SCHEDULE, 11)
             ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, fpb)
             cut = D * 1777 + 5
             got = np.concatenate([ch(iq[:cut]), ch(iq[cut:])])
             assert np.array_equal(got, ref), fpb
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, magnitude=True) as ch:
+        ch.set_option(L.PFB_OPT_SCHEDULE, 0)
+        ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, 512)
+        ref = ch(iq)
+        for fpb in (12, 24, 32):
+            ch.reset()
+            ch.set_option(L.PFB_OPT_SCHEDULE, 11)
+            ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, fpb)
+            assert np.array_equal(ch(iq), ref), ("magnitude", fpb)
 
 
 def test_iq_file_front_end(oracle, tmp_path):
