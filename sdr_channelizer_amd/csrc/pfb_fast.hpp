@@ -1218,6 +1218,9 @@ struct FastKernel {
   // (A variant of this kernel for channel-major handles -- the last pass writing frame-major scratch tiles that the FFT
   // team moved into place transposed -- measured slower than frame-major slabs plus a transpose kernel, 7.4 against 6.4 ms
   // per 2^30 samples at M = 1024, and was removed: DESIGN.md section 5.4.)
+  // (The window as a ring of registers -- blocks of 10 steps at M = 1024, no slide: 50 fewer VALU instructions per two steps --
+  // measured 0.611-0.612 against 0.608-0.609, nothing on M = 560 / 400 / 320: the FIR team's issue slots are not what the
+  // kernel waits for; not kept.  The pipelined single-wave kernel keeps its ring, run_overlap_ring.)
   template <bool INTERIOR, int MAGSEL = -1>
   PFB_DEV void fir_team(const KernelParams& p, const Consts& k, float2* bufs, long long f_begin, int nch) {
     const int tid = threadIdx.x;
