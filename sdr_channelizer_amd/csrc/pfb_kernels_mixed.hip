@@ -20,7 +20,7 @@
 namespace pfb {
 
 //                 M    P   D  CPT FMT               C NP R0 R1 R2 RS0 RS1 RS2 FS  PP     MINW  TW_TABLE
-using Cfg12x12i16 = FastCfg<12, 12, 12, 1, PFB_FMT_INT16_IQ, 8, 2, 6, 2, 1, 2, 7, 0, 38, true, 3>;
+using Cfg12x12i16 = FastCfg<12, 12, 12, 1, PFB_FMT_INT16_IQ, 8, 2, 6, 2, 1, 2, 7, 0, 38, true, 2>;  // (two waves per SIMD: its 168-register state does not fit three)
 using Cfg24x12i16 = FastCfg<24, 12, 24, 1, PFB_FMT_INT16_IQ, 8, 2, 12, 2, 1, 2, 13, 0, 26, true, 4>;
 // (M = 25: 5 x 5 leaves the final pass 5-channel = 40-byte store runs; 0.34-0.39 of roofline -- another frame stride,
 // chunks of 16 frames per segment: no better)
