@@ -82,3 +82,39 @@ def test_fused_kernels_agree_with_the_generic_kernel(case):
     assert got.shape == want.shape, (case, kw)
     scale = max(float(np.abs(want).max()), 1e-30)
     assert float(np.abs(got - want).max()) / scale < 3e-6, (case, M, fmt, kw)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("PFB_ORACLE_FUZZ_CASES", "460"))))  # 10 per shape
+def test_fused_kernels_agree_with_the_oracle(oracle, case):
+    """The same seeded walk over shapes, formats, switches, schedules, run lengths and call cuts -- against the float64 CPU
+    oracle (oracle/pfb_oracle.c) instead of the generic kernel, at lengths the oracle finishes in a moment: the fast and
+    the generic kernel share tables and host code, the oracle shares nothing with either."""
+    from oracle.pfb_oracle import OracleConfig
+    rng = np.random.default_rng(7000 + case)
+    M, P, D, fmts, scheds = SHAPES[case % len(SHAPES)]
+    fmt = fmts[int(rng.integers(len(fmts)))]
+    frames = int(rng.integers(30, 400 if M <= 256 else 120))
+    n = frames * D + int(rng.integers(0, D))
+    iq, bw = make_input(rng, n, fmt)
+    h = (rng.standard_normal(M * P) / M).astype(np.float32)
+    kw = dict(fftshift=bool(rng.integers(2)), conjugate_input=bool(rng.integers(2)), derotate=bool(rng.integers(2)),
+              input_offset=int(rng.integers(-1, D)))
+    channel_major = bool(rng.integers(2))
+    cuts = sorted({0, n, *(int(c) for c in rng.integers(0, n, size=int(rng.integers(0, 3))))})
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, channel_major=channel_major, **kw) as ch:
+        ch.set_option(L.PFB_OPT_KERNEL, 2)
+        if rng.random() < 0.6:
+            ch.set_option(L.PFB_OPT_SCHEDULE, int(scheds[int(rng.integers(len(scheds)))]))
+        if rng.random() < 0.5:
+            ch.set_option(L.PFB_OPT_FRAMES_PER_BLOCK, int(rng.choice([8, 12, 24, 32, 40, 64, 100, 256])))
+        parts = [ch(iq[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert ch.last_kernel.startswith("pfb_fast")
+        got = np.concatenate([q for q in parts if q.size], axis=1 if channel_major else 0) if any(q.size for q in parts) else parts[0]
+    x = (iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)) if fmt == "cf32" else oracle.unpack(iq, bw)
+    cfg = OracleConfig(M, P, D, fftshift=kw["fftshift"], conj_input=kw["conjugate_input"], derotate=kw["derotate"], off=kw["input_offset"])
+    want = oracle.channelize(x, h.astype(np.float64), cfg, "fft" if (M & (M - 1)) == 0 else "polyphase")
+    if channel_major:
+        want = want.T
+    assert got.shape == want.shape, (case, M, fmt, kw)
+    scale = max(float(np.abs(want).max()), 1e-30)
+    assert float(np.abs(got - want).max()) / scale < 1e-5, (case, M, fmt, kw)   # the fp32 tolerance of the parity tests
