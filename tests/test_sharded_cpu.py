@@ -122,7 +122,7 @@ def test_segment_bounds():
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("mode,world", [("p2p", 2), ("allgather", 2), ("p2p", 3), ("allgather", 4)])
+@pytest.mark.parametrize("mode,world", [("p2p", 2), ("allgather", 2), ("p2p", 3), ("allgather", 4), ("p2p", 8)])  # 8: the driver's node
 def test_two_rank_time_sharding_matches_single_stream(mode, world):
     total = D * 400
     taps = np.random.default_rng(0).standard_normal(M * P)
