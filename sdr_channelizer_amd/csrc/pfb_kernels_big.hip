@@ -44,7 +44,8 @@ using Cfg560x12i8t2 =
 
 // complex float32 input at the training script's band count (generate_channelized_training_iq.m:95-100 channelizes data
 // that only exists as complex doubles in MATLAB's memory) and at cfg4's: the lockstep plans, whose one column per thread
-// leaves room for 8-byte samples (the team plans' two-column FIR window spills 40-100 registers with them)
+// leaves room for 8-byte samples (the 4-frame team plans' two-column FIR window spills 40-100 registers with them; the
+// 2-frame teams further down do not, and are the defaults since round 3: these two stay as variant 1)
 using Cfg560x12f32 = FastCfg<560, 12, 560, 1, PFB_FMT_CF32, 7, 3, 10, 8, 7, 56, 71, 82, 600, false, 3, true>;
 using Cfg1024x16f32b = FastCfg<1024, 16, 1024, 1, PFB_FMT_CF32, 8, 3, 8, 8, 16, 128, 128, 65, 1040, false, 1, true>;
 
@@ -60,6 +61,14 @@ using Cfg1024x16i16q =
 using Cfg1024x16i16d =
     FastCfg<1024, 16, 1024, 4, PFB_FMT_INT16_IQ, 8, 3, 16, 16, 4, 64, 68, 260, 1088, false, 2, true, true>;
 
+// complex float32 input on the team plans: with chunks of TWO frames the FIR thread's state (13- / 17-row window, two row
+// sets of 8-byte samples in flight) fits where the 4-frame teams spilled 40-100 registers
+// (the same 2-frame teams on int16 cfg4 -- 10 waves, 128 registers, still one workgroup per CU -- : 0.52 against 0.60 for the
+// 4-frame teams; not registered)
+using Cfg560x12f32t2 =
+    FastCfg<560, 12, 560, 2, PFB_FMT_CF32, 2, 3, 14, 10, 4, 40, 60, 140, 600, false, 4, false>;
+using Cfg1024x16f32t2 =
+    FastCfg<1024, 16, 1024, 2, PFB_FMT_CF32, 2, 3, 16, 16, 4, 64, 68, 260, 1088, false, 3, false>;
 // (M = 560 on schedule 13 -- 5 waves per workgroup, chunks of 5 frames, one frame per wave, 124 registers, three workgroups
 // per CU -- is bit-identical to the team plans and slower: 0.37-0.39 of the roofline against 0.524 in one process; removed)
 static const FastEntry kRows[] = {
@@ -76,8 +85,11 @@ static const FastEntry kRows[] = {
     entry<Cfg560x12i8t2>("pfb_fast<M560,P12,D560,int8>", 512, 6),
     entry<Cfg560x12i8t>("pfb_fast<M560,P12,D560,int8,4f>", 512, 6),
     entry<Cfg560x12i8>("pfb_fast<M560,P12,D560,int8,9w>", 252, 0),
-    entry<Cfg560x12f32>("pfb_fast<M560,P12,D560,cf32>", 252, 0),
-    entry<Cfg1024x16f32b>("pfb_fast<M1024,P16,D1024,cf32>", 256, 0),
+    // complex float32: the 2-frame teams (0.61 / 0.63 of the roofline) ahead of the lockstep plans (0.47 / 0.42)
+    entry<Cfg560x12f32t2>("pfb_fast<M560,P12,D560,cf32>", 512, 6),
+    entry<Cfg560x12f32>("pfb_fast<M560,P12,D560,cf32,9w>", 252, 0),
+    entry<Cfg1024x16f32t2>("pfb_fast<M1024,P16,D1024,cf32>", 512, 6),
+    entry<Cfg1024x16f32b>("pfb_fast<M1024,P16,D1024,cf32,16w>", 256, 0),
     entry<Cfg1024x16i16d>("pfb_fast<M1024,P16,D1024,int16,duo>", 256, 13),
 };
 
