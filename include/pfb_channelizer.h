@@ -82,10 +82,13 @@ enum {
   PFB_FLAG_FFTSHIFT = 1u << 0,        /* fftshift(out,2): create_pdws_channelized.m:60 */
   PFB_FLAG_CONJUGATE_INPUT = 1u << 1, /* iq' quirk: channelizer_example.m:23           */
   PFB_FLAG_DEROTATE = 1u << 2,        /* y_k[m] *= e^{-j2 pi k m D/M} (identity if D=M) */
-  PFB_FLAG_MAGNITUDE = 1u << 3        /* fused abs(): `out` receives float32 |y_k[m]| instead of  */
+  PFB_FLAG_MAGNITUDE = 1u << 3,       /* fused abs(): `out` receives float32 |y_k[m]| instead of  */
                                       /* complex64 (abs(channelizer(x)), channelizer_example.m:56; */
                                       /* mag = abs(iq), create_pdws_channelized.m:67): half the    */
                                       /* output bytes                                              */
+  PFB_FLAG_POWER = 1u << 4            /* with PFB_FLAG_MAGNITUDE: |y_k[m]|^2 instead of |y_k[m]|   */
+                                      /* (no square root; what a detector that thresholds power    */
+                                      /* wants).  Without PFB_FLAG_MAGNITUDE: PFB_ERR_BAD_ARG      */
 };
 
 enum {

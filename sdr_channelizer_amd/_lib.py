@@ -28,6 +28,7 @@ PFB_FREQ_ORDER_FFT, PFB_FREQ_ORDER_CENTERED = 0, 1
 PFB_FMT_INT8_IQ, PFB_FMT_INT16_IQ, PFB_FMT_CF32 = 0, 1, 2
 PFB_LAYOUT_FRAME_MAJOR, PFB_LAYOUT_CHANNEL_MAJOR = 0, 1
 PFB_FLAG_FFTSHIFT, PFB_FLAG_CONJUGATE_INPUT, PFB_FLAG_DEROTATE, PFB_FLAG_MAGNITUDE = 1, 2, 4, 8
+PFB_FLAG_POWER = 16  # with PFB_FLAG_MAGNITUDE: |y|^2 instead of |y|
 PFB_MEM_HOST, PFB_MEM_DEVICE = 0, 1
 PFB_OPT_KERNEL, PFB_OPT_FRAMES_PER_BLOCK, PFB_OPT_HOST_CHUNK_SAMPLES, PFB_OPT_NONTEMPORAL, PFB_OPT_PROFILE, PFB_OPT_XCD_REMAP = 0, 1, 2, 3, 4, 5
 PFB_OPT_SCHEDULE, PFB_OPT_GRID, PFB_OPT_TILE_WAVES, PFB_OPT_EXPERIMENT, PFB_OPT_VARIANT = 6, 7, 8, 9, 10

@@ -73,7 +73,7 @@ class Channelizer:
     def __init__(self, num_bands: int, *, taps: np.ndarray | None = None, taps_per_band: int = 12,
                  stopband_atten: float = 80.0, decimation: int | None = None, sample_format: str = "int16",
                  bit_width: int = 12, channel_major: bool = False, fftshift: bool = False,
-                 conjugate_input: bool = False, derotate: bool = False, magnitude: bool = False,
+                 conjugate_input: bool = False, derotate: bool = False, magnitude: bool = False, power: bool = False,
                  input_offset: int = -1, device: int = -1):
         self._h = C.c_void_p()
         lib = L.load()
@@ -91,11 +91,14 @@ class Channelizer:
         self.bit_width = int(bit_width)
         self.channel_major = bool(channel_major)
         self.device = device
+        self.power = bool(power)          # float32 |y|^2 out (implies the fused-magnitude output path, no square root)
+        magnitude = bool(magnitude) or self.power
         self.magnitude = bool(magnitude)  # fused abs(channelizer(x)): float32 out
         self.fftshift = bool(fftshift)
         self._shard_cb = None  # keeps the ctypes halo-exchange callback alive while attached
         flags = (L.PFB_FLAG_FFTSHIFT if fftshift else 0) | (L.PFB_FLAG_CONJUGATE_INPUT if conjugate_input else 0) \
-            | (L.PFB_FLAG_DEROTATE if derotate else 0) | (L.PFB_FLAG_MAGNITUDE if magnitude else 0)
+            | (L.PFB_FLAG_DEROTATE if derotate else 0) | (L.PFB_FLAG_MAGNITUDE if magnitude else 0) \
+            | (L.PFB_FLAG_POWER if self.power else 0)
         cfg = L.PfbConfig(C.sizeof(L.PfbConfig), M, self.taps_per_band, self.decimation,
                           taps.ctypes.data_as(C.POINTER(C.c_float)), self.fmt, self.bit_width,
                           L.PFB_LAYOUT_CHANNEL_MAJOR if channel_major else L.PFB_LAYOUT_FRAME_MAJOR, flags,

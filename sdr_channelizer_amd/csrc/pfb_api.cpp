@@ -566,6 +566,7 @@ int pfb_create(const pfb_config* cfg, pfb_handle** out) {
   }
   if (cfg->sample_format > PFB_FMT_CF32) return PFB_ERR_BAD_FORMAT;
   if (cfg->output_layout > PFB_LAYOUT_CHANNEL_MAJOR) return PFB_ERR_BAD_ARG;
+  if ((cfg->flags & PFB_FLAG_POWER) && !(cfg->flags & PFB_FLAG_MAGNITUDE)) return PFB_ERR_BAD_ARG;
   int bw = (int)cfg->bit_width;
   if (cfg->sample_format == PFB_FMT_INT8_IQ && (bw < 1 || bw > 8)) return PFB_ERR_BAD_FORMAT;
   if (cfg->sample_format == PFB_FMT_INT16_IQ && (bw < 1 || bw > 16)) return PFB_ERR_BAD_FORMAT;

@@ -85,6 +85,12 @@ template <> struct SampleT<PFB_FMT_CF32> {
   }
 };
 
+// the float32 a PFB_FLAG_MAGNITUDE handle stores for an output y: |y|, or |y|^2 with PFB_FLAG_POWER
+static __device__ __forceinline__ float mag_out(float re, float im, unsigned flags) {
+  const float m2 = re * re + im * im;
+  return (flags & PFB_FLAG_POWER) ? m2 : sqrtf(m2);
+}
+
 static inline int bytes_per_sample(int fmt) {
   return fmt == PFB_FMT_INT8_IQ ? 2 : (fmt == PFB_FMT_INT16_IQ ? 4 : 8);
 }

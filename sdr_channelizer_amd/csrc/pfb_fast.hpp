@@ -574,7 +574,7 @@ struct FastKernel {
             for (int k = 0; k < R; ++k) {
               int col = kk + k * KK + shift;
               col = col >= M ? col - M : col;
-              if (active) stage[fc * SR + col] = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
+              if (active) stage[fc * SR + col] = mag_out(x[k].x, x[k].y, p.flags);
             }
             team_sync<true>();
             constexpr int NV = C * M / 4;  // float4s in the chunk
@@ -631,7 +631,7 @@ struct FastKernel {
             for (int k = 0; k < R; ++k) {
               v2f v = x[k];
               if (mag) {
-                *reinterpret_cast<float*>(ptr) = sqrtf(v.x * v.x + v.y * v.y);
+                *reinterpret_cast<float*>(ptr) = mag_out(v.x, v.y, p.flags);
               } else {
                 v = derot(v, k);
                 store_c64(reinterpret_cast<float2*>(ptr), v, p.nontemporal);
@@ -644,7 +644,7 @@ struct FastKernel {
           } else if (MAGSEL == 1 || (MAGSEL < 0 && (p.flags & PFB_FLAG_MAGNITUDE))) {  // fused abs(): 4 bytes per channel instead of 8
             float* rowm = reinterpret_cast<float*>(p_out) + f0 * M + fc * M;
 #pragma unroll
-            for (int k = 0; k < R; ++k) *slot(rowm, k) = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
+            for (int k = 0; k < R; ++k) *slot(rowm, k) = mag_out(x[k].x, x[k].y, p.flags);
           } else {
             float2* row = p_out + f0 * M + fc * M;
             // (probed: R/2 16-byte stores per lane instead of R 8-byte ones -- same bytes, half the store instructions,
@@ -1374,7 +1374,7 @@ struct FastKernel {
         if constexpr (MAG) {
           float* rowm = reinterpret_cast<float*>(p.out) + f * M;
 #pragma unroll
-          for (int k = 0; k < R; ++k) *slot(rowm, k) = sqrtf(x[it][k].x * x[it][k].x + x[it][k].y * x[it][k].y);
+          for (int k = 0; k < R; ++k) *slot(rowm, k) = mag_out(x[it][k].x, x[it][k].y, p.flags);
         } else {
           float2* row = p.out + f * M;
 #pragma unroll
@@ -2086,7 +2086,7 @@ struct FastKernel {
         const long long f = tf0 + fr;
         if (f < p.frames) {
           const long long idx = (long long)col * p.out_ld + p.out_frame0 + f;
-          if (mag) reinterpret_cast<float*>(p.out)[idx] = sqrtf(v[i].x * v[i].x + v[i].y * v[i].y);
+          if (mag) reinterpret_cast<float*>(p.out)[idx] = mag_out(v[i].x, v[i].y, p.flags);
           else store_c64(p.out + idx, v[i], p.nontemporal);
         }
       }
@@ -2179,7 +2179,7 @@ struct SegKernel {
             int col = kk + k * KK + shift;
             col = col >= M ? col - M : col;
             const long long o = cm ? (long long)col * p.out_ld + p.out_frame0 + f : f * M + col;
-            if (mag) reinterpret_cast<float*>(p.out)[o] = sqrtf(x[k].x * x[k].x + x[k].y * x[k].y);
+            if (mag) reinterpret_cast<float*>(p.out)[o] = mag_out(x[k].x, x[k].y, p.flags);
             else if (MAGSEL >= 0) *reinterpret_cast<v2f*>(&p.out[o]) = x[k];
             else store_c64(&p.out[o], x[k], p.nontemporal);
           }

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) pfb_generic_kernel(const KernelParams p, 
         v = make_float2(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y);  // * conj(w)
       }
       const int col = (p.flags & PFB_FLAG_FFTSHIFT) ? (k + half_shift) % M : k;
-      if (p.flags & PFB_FLAG_MAGNITUDE) reinterpret_cast<float*>(p.out)[f * M + col] = sqrtf(v.x * v.x + v.y * v.y);
+      if (p.flags & PFB_FLAG_MAGNITUDE) reinterpret_cast<float*>(p.out)[f * M + col] = mag_out(v.x, v.y, p.flags);
       else p.out[f * M + col] = v;
     }
   } else {  // CHANNEL_MAJOR: consecutive threads write consecutive frames of one channel
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) pfb_generic_kernel(const KernelParams p, 
       }
       const int col = (p.flags & PFB_FLAG_FFTSHIFT) ? (k + half_shift) % M : k;
       const long long o = (long long)col * p.out_ld + p.out_frame0 + f;
-      if (p.flags & PFB_FLAG_MAGNITUDE) reinterpret_cast<float*>(p.out)[o] = sqrtf(v.x * v.x + v.y * v.y);
+      if (p.flags & PFB_FLAG_MAGNITUDE) reinterpret_cast<float*>(p.out)[o] = mag_out(v.x, v.y, p.flags);
       else p.out[o] = v;
     }
   }

@@ -107,6 +107,7 @@ def test_create_validates_arguments():
     assert lib.pfb_create(C.byref(cfg(num_channels=1)), C.byref(h)) == L.PFB_ERR_BAD_ARG
     assert lib.pfb_create(C.byref(cfg(decimation=65)), C.byref(h)) == L.PFB_ERR_BAD_ARG
     assert lib.pfb_create(C.byref(cfg(input_offset=64)), C.byref(h)) == L.PFB_ERR_BAD_ARG
+    assert lib.pfb_create(C.byref(cfg(flags=L.PFB_FLAG_POWER)), C.byref(h)) == L.PFB_ERR_BAD_ARG  # |y|^2 is an option of the magnitude output
     assert lib.pfb_create(C.byref(cfg(sample_format=7)), C.byref(h)) == L.PFB_ERR_BAD_FORMAT
     assert lib.pfb_create(C.byref(cfg(sample_format=L.PFB_FMT_INT8_IQ, bit_width=12)), C.byref(h)) == L.PFB_ERR_BAD_FORMAT
     assert lib.pfb_process(None, None, 0, None, 0, None, 0) == L.PFB_ERR_BAD_ARG

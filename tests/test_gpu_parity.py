@@ -582,6 +582,19 @@ def test_fused_magnitude_output(oracle, M, P, D, fmt, bw, kw):
         m = m.T
     assert m.dtype == np.float32 and m.shape == want.shape
     assert np.abs(m - want).max() / want.max() < REL_TOL
+    # PFB_FLAG_POWER: |y|^2 through the same stores, no square root -- and exactly the square the magnitude was the root of
+    with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, power=True, fftshift=True, **kw) as ch:
+        pw = ch(iq)
+        assert ch.last_kernel.startswith("pfb_fast")
+        ch.set_option(L.PFB_OPT_KERNEL, 1)
+        ch.reset()
+        pw_generic = ch(iq)
+    if kw.get("channel_major"):
+        pw, pw_generic = pw.T, pw_generic.T
+    assert pw.dtype == np.float32 and pw.shape == want.shape
+    assert np.abs(pw - want ** 2).max() / (want ** 2).max() < 2 * REL_TOL
+    assert np.abs(pw_generic - want ** 2).max() / (want ** 2).max() < 2 * REL_TOL
+    assert np.all(np.abs(np.sqrt(pw) - m) <= np.spacing(m))
 
 
 def test_misaligned_device_buffer_and_cf32(oracle):
