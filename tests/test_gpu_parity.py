@@ -836,3 +836,37 @@ def test_default_run_length_follows_the_call_and_keeps_the_bits(M, P, D, fmt, bw
         cuts = np.concatenate([[0], np.cumsum(lens) * D - 3, [n]])
         parts = [a(iq[s:e]) for s, e in zip(cuts[:-1], cuts[1:])]
         assert torch.equal(torch.cat([q for q in parts if q.numel()]), want)
+
+
+@pytest.mark.parametrize("M,P", [(8, 12), (64, 12), (256, 8), (560, 12), (1024, 16)])
+def test_non_finite_samples_stay_inside_their_window(M, P):
+    """complex float32 input with one NaN and one Inf: exactly the frames whose M*P-sample window covers them are non-finite
+    (every channel of them: the DFT mixes all branches), every other frame is bit-identical to the clean stream's -- nothing
+    leaks through the carried state, the fused kernels and the generic one agree on which frames those are."""
+    D = M
+    n = D * 400
+    rng = np.random.default_rng(5)
+    iq = (rng.standard_normal((n, 2)) * 0.25).astype(np.float32)
+    bad = iq.copy()
+    i_nan, i_inf = D * 101 + 3, D * 250 + D // 2
+    bad[i_nan, 0] = np.nan
+    bad[i_inf, 1] = np.inf
+    h = (rng.standard_normal(M * P) / M).astype(np.float32)
+    h[h == 0] = 1e-3   # every tap touches its sample
+    with Channelizer(M, taps=h, sample_format="cf32", bit_width=1) as ch:
+        clean = ch(iq)
+        ch.reset()
+        cut = D * 180 + 1
+        got = np.concatenate([ch(bad[:cut]), ch(bad[cut:])])   # the Inf arrives in the second call
+        assert ch.last_kernel.startswith("pfb_fast")
+        ch.set_option(L.PFB_OPT_KERNEL, 1)
+        ch.reset()
+        gen = ch(bad)
+    hit = np.zeros(n // D, bool)
+    for i in (i_nan, i_inf):   # frame m reads samples [m*D + D - M*P, m*D + D - 1]: frames i // D ... (i + M*P - D) // D
+        hit[i // D: (i + M * P - D) // D + 1] = True
+    finite = np.isfinite(got).all(axis=1)
+    assert np.array_equal(~finite, hit), (np.flatnonzero(~finite)[[0, -1]], np.flatnonzero(hit)[[0, -1]])
+    assert not np.isfinite(got[hit]).any()
+    assert np.array_equal(got[~hit], clean[~hit])
+    assert np.array_equal(np.isfinite(gen).all(axis=1), finite)
