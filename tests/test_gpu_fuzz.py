@@ -57,6 +57,7 @@ def test_fused_kernels_agree_with_the_generic_kernel(case):
     kw = dict(fftshift=bool(rng.integers(2)), conjugate_input=bool(rng.integers(2)), derotate=bool(rng.integers(2)),
               magnitude=bool(rng.integers(2)), channel_major=bool(rng.integers(2)),
               input_offset=int(rng.integers(-1, D)))
+    kw["power"] = kw["magnitude"] and bool(rng.integers(2))   # |y|^2 instead of |y|
     cuts = sorted({0, n, *(int(c) for c in rng.integers(0, n, size=int(rng.integers(0, 3))))})
     with Channelizer(M, taps=h, decimation=D, sample_format=fmt, bit_width=bw, **kw) as ch:
         ch.set_option(L.PFB_OPT_KERNEL, 1)
